@@ -1,0 +1,225 @@
+/*
+ * melo_gan_hip.h -- C-ABI of libmelogan_hip.so (gfx950 / MI355X).
+ *
+ * The reference (kaushik87599/Melo-GAN) has no FFI: its hot path is a set of
+ * torch.nn modules (ATen ops).  Each entry point below replaces the ATen op(s)
+ * that the cited reference lines dispatch; the host side (melo-gan_amd/) calls
+ * them through ctypes with raw device pointers owned by PyTorch's allocator.
+ *
+ * Conventions
+ *   - All tensors are fp32, CHANNELS-LAST: activations (B, T, C) contiguous in C
+ *     (the layout of the reference's `notes` tensors; the reference permutes to
+ *     (B, C, T) for torch's Conv1d -- src/gan/models.py:159, ed_model.py:65 --
+ *     this library never does).
+ *   - Weights keep the reference's state_dict layouts: Conv1d (Cout, Cin, K),
+ *     ConvTranspose1d (Cin, Cout, K), Linear (out, in).
+ *   - Every function enqueues on `stream` (a hipStream_t) and returns without
+ *     synchronising.  No allocation, no retained pointers.
+ *   - Return 0 on success; <0 on error: -1 bad argument/shape, -2 unsupported
+ *     configuration, -3 workspace too small, -4 HIP runtime error.  The message is
+ *     available from mg_last_error() (thread-local).
+ */
+#ifndef MELO_GAN_HIP_H
+#define MELO_GAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mg_stream_t; /* hipStream_t */
+
+/* activation ids (epilogue `act`, and `gact` = which derivative to apply) */
+enum { MG_ACT_NONE = 0, MG_ACT_RELU = 1, MG_ACT_LRELU = 2, MG_ACT_GELU = 3, MG_ACT_TANH = 4 };
+
+/* Fused epilogue of the window-GEMM kernels.  For an output element v=acc:
+ *   v += bias[n];  v = v*scale[n] + shift[n];  zout[idx] = v;  v = act(v);
+ *   v *= act'(gref[idx]) (gact);  v *= emul[idx];  v *= gscale[n];
+ *   y = accumulate ? y + v : v
+ * Null pointers skip the corresponding stage.  gref semantics per gact:
+ *   RELU  : gref is the forward OUTPUT a (mask a>0)
+ *   LRELU : gref is the forward output a (a>0 ? 1 : 0.2)
+ *   GELU  : gref is the forward PRE-activation z (exact erf form)
+ *   TANH  : gref is the forward output a (1 - a*a)
+ */
+typedef struct mg_epilogue {
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    float* zout;
+    int act;
+    const float* gref;
+    int gact;
+    const float* emul;
+    const float* gscale;
+    int accumulate;
+} mg_epilogue;
+
+int mg_version(void);
+const char* mg_last_error(void);
+
+/* ---- window GEMM: Conv1d / ConvTranspose1d / Linear, forward and data-gradient ----
+ *
+ * mg_conv1d_gather: y[b,t,n] = EPI( sum_{k,c} x[b, t*stride + k - (K-1)/2, c] * W(n,c,kw) )
+ *   kw = flip ? K-1-k : k ;  W(n,c,k) = w[n*w_sn + c*w_sc + k].
+ *   Tout = (Tin + 2*((K-1)/2) - K)/stride + 1.   stride in {1,2}, K in {1,3,5}.
+ *   Replaces: nn.Conv1d forward (src/gan/models.py:141-145, ed_model.py:28, src/ae/model.py:11-19)
+ *             with w_sn=Cin*K, w_sc=K;  nn.Linear forward (K=1,T=1; w_sn=in, w_sc=1);
+ *             ConvTranspose1d data-gradient (stride 2; w_sn=Cout*K, w_sc=K);
+ *             Conv1d stride-1 data-gradient (flip=1; w_sn=K, w_sc=Cin*K);
+ *             Linear data-gradient (K=1; w_sn=1, w_sc=in).
+ *   x batch stride xbs, y batch stride ybs (elements; 0 => dense).
+ */
+int mg_conv1d_gather(const float* x, const float* w, float* y,
+                     int B, int Tin, int Cin, int N, int K, int stride, int flip,
+                     int w_sn, int w_sc, long xbs, long ybs,
+                     const mg_epilogue* epi, mg_stream_t stream);
+
+/* mg_conv1d_scatter2: stride-2, K=5, padding 2, output_padding 1 transposed convolution
+ *   y[b,t,n] = EPI( sum_{k,c : t+2-k even} x[b,(t+2-k)/2,c] * W(n,c,k) ),  t < Tout,
+ *   Tout = 2*Tin (ConvTranspose1d forward) or 2*Tin-1 (data-gradient of a stride-2 Conv1d whose
+ *   input length was odd).
+ *   Replaces: nn.ConvTranspose1d forward (src/gan/models.py:56-62, src/ae/model.py:66-74)
+ *             with w_sn=K, w_sc=Cout*K;  Conv1d stride-2 data-gradient (src/gan/models.py:141-145
+ *             backward; w_sn=K... i.e. n=Cin: w_sn=K, w_sc=Cin*K).
+ */
+int mg_conv1d_scatter2(const float* x, const float* w, float* y,
+                       int B, int Tin, int Cin, int N, int Tout,
+                       int w_sn, int w_sc, long xbs, long ybs,
+                       const mg_epilogue* epi, mg_stream_t stream);
+
+/* ---- weight gradient ----
+ * out[a][b][k] = sum over segments, batches, u of  S[bt,u,a] * L[bt, u*stride + k - (K-1)/2, b]
+ *   S: (nb, Ts, A) "small" tensor, L: (nb, Tl, Bc) "large" tensor (zero outside [0,Tl)).
+ *   Conv1d   wgrad: S=dy (A=Cout), L=x  (Bc=Cin)  -> (Cout,Cin,K)
+ *   ConvT1d  wgrad: S=x  (A=Cin),  L=dy (Bc=Cout) -> (Cin,Cout,K)
+ *   Linear   wgrad: Ts=Tl=1,K=1: S=dy (A=out), L=x (Bc=in) -> (out,in)
+ * Up to two (S,L,nb) segments are summed (segment 1 may have nb1=0).
+ * `work` must hold mg_wgrad_workspace_bytes(...) bytes.  Deterministic (no atomics).
+ */
+size_t mg_wgrad_workspace_bytes(int A, int Bc, int K, int nb_total, int Ts);
+int mg_wgrad(const float* s0, const float* l0, int nb0,
+             const float* s1, const float* l1, int nb1,
+             float* out, int Ts, int Tl, int A, int Bc, int K, int stride,
+             void* work, size_t work_bytes, mg_stream_t stream);
+
+/* ---- per-channel column reductions over rows of a (R, C) matrix ----
+ * sum[c] = sum_r x[r,c] (and sumsq if sumsq != NULL).  Used for bias gradients and BN statistics.
+ * `work`: mg_colsum_workspace_bytes(C). */
+size_t mg_colsum_workspace_bytes(int C);
+int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq,
+              void* work, size_t work_bytes, mg_stream_t stream);
+
+/* ---- BatchNorm1d, training mode, fused with ReLU (src/gan/models.py:57-61, src/ae/model.py:12-21) ----
+ * z: (R, C) pre-BN (R = B*T).  Computes batch mean / biased var, a = relu((z-mean)*invstd*gamma+beta),
+ * saves mean/invstd, updates running_mean/var (momentum 0.1, unbiased var) -- also under no_grad.
+ * act: MG_ACT_RELU or MG_ACT_NONE. */
+size_t mg_bn_workspace_bytes(int C);
+int mg_bn_train_fwd(const float* z, float* a, long R, int C,
+                    const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* save_mean, float* save_invstd, int act,
+                    void* work, size_t work_bytes, mg_stream_t stream);
+/* backward: da (grad wrt a), a (forward output, for the ReLU mask), z.  Produces dz, dgamma, dbeta. */
+int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, long R, int C,
+                    const float* gamma, const float* save_mean, const float* save_invstd,
+                    float* dgamma, float* dbeta, int act,
+                    void* work, size_t work_bytes, mg_stream_t stream);
+/* eval mode: a = act((z-running_mean)/sqrt(running_var+eps)*gamma+beta) */
+int mg_bn_eval_fwd(const float* z, float* a, long R, int C, const float* gamma, const float* beta,
+                   const float* running_mean, const float* running_var, float eps, int act,
+                   mg_stream_t stream);
+/* fold eval-mode BN + conv bias into per-channel scale/shift (ed_model.py:37, eval mode) */
+int mg_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+               const float* conv_bias, float eps, float* scale, float* shift, int C, mg_stream_t stream);
+
+/* ---- mean over time (AdaptiveAvgPool1d(1); src/gan/models.py:148, ed_model.py:60) ---- */
+int mg_meanT_fwd(const float* a, float* h, int B, int T, int C, mg_stream_t stream);
+/* dz[b,t,c] = dh[b,c]/T * act'(gref[b,t,c]) * gscale[c]   (gref/gscale may be NULL) */
+int mg_meanT_bwd(const float* dh, float* dz, int B, int T, int C,
+                 const float* gref, int gact, const float* gscale, mg_stream_t stream);
+
+/* ---- LayerNorm over the last dim (src/gan/feature_encoder.py:19), D <= 64 ---- */
+int mg_layernorm_fwd(const float* x, float* y, float* xhat, int B, int D,
+                     const float* gamma, const float* beta, float eps, mg_stream_t stream);
+int mg_layernorm_bwd_params(const float* dy, const float* xhat, float* dgamma, float* dbeta,
+                            int B, int D, mg_stream_t stream);
+
+/* ---- critic head (src/gan/models.py:157,165-169): s[b] = <[f[b], emb[b % Be]], w> + bias ---- */
+int mg_dhead_fwd(const float* f, const float* emb, const float* w, const float* bias, float* s,
+                 int B, int Be, int F, int E, mg_stream_t stream);
+/* dU[b,j] = ds[b]*w[j]*lrelu'(f[b,j]); demb[be,j] (+)= sum over b%Be==be of ds[b]*w[F+j] (if demb) */
+int mg_dhead_bwd(const float* ds, const float* f, const float* w, float* dU, float* demb,
+                 int B, int Be, int F, int E, int nb_emb, mg_stream_t stream);
+/* dw[j<F] = sum_{b<nb} ds[b] f[b,j] + sum_{b<ng} gf[b,j];  dw[F+j] = sum_{b<nb} ds[b] emb[b%Be,j];
+ * dbias = sum_{b<nb} ds[b] */
+int mg_dhead_wgrad(const float* ds, const float* f, const float* emb, const float* gf,
+                   float* dw, float* dbias, int nb, int ng, int Be, int F, int E, mg_stream_t stream);
+
+/* ---- WGAN-GP pieces (src/gan/utils.py:75-90) ---- */
+/* xhat[b,:] = alpha[b]*real[b,:] + (1-alpha[b])*fake[b,:]   (n = T*C elements per sample) */
+int mg_gp_interp(const float* real, const float* fake, const float* alpha, float* xhat,
+                 int B, long n, mg_stream_t stream);
+/* norms[b] = ||g[b,:]||_2 ; gp = mean((norm-1)^2) ; gbar[b,:] = coef*(2/B)*(norm-1)/norm * g[b,:] */
+int mg_gp_penalty(const float* g, float* gbar, float* norms, float* gp, float coef,
+                  int B, long n, mg_stream_t stream);
+
+/* ---- losses ---- */
+/* loss_d = mean(s[nb:2nb]) - mean(s[0:nb]) + lambda_gp*gp ; out[0]=loss_d out[1]=mean_real out[2]=mean_fake */
+int mg_wgan_d_loss(const float* s, const float* gp, float lambda_gp, float* out, int nb, mg_stream_t stream);
+/* cross entropy over C<=32 classes: loss = mean_b(-log softmax[b,y_b]); dlogits = coef*(softmax-onehot)/B */
+int mg_softmax_ce(const float* logits, const int64_t* target, float* loss, float* dlogits,
+                  float coef, int B, int C, mg_stream_t stream);
+/* out[0] = -mean(s[0:B]) */
+int mg_neg_mean(const float* s, float* out, int B, mg_stream_t stream);
+
+/* ---- elementwise helpers ---- */
+int mg_fill(float* x, float v, long n, mg_stream_t stream);
+int mg_axpby(const float* x, float* y, float a, float b, long n, mg_stream_t stream); /* y = a*x + b*y */
+/* dst[r, doff + j] = src[r, soff + j] for j < ncols (row-major 2-D copy; accumulate adds) */
+int mg_copy_cols(const float* src, int sld, int soff, float* dst, int dld, int doff,
+                 int rows, int ncols, int accumulate, mg_stream_t stream);
+/* (B, C, L) <-> (B, L, C): out[b, l, c] = in[b, c, l]  (src/gan/models.py:70 view + :73 permute) */
+int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, mg_stream_t stream);
+/* y = x * act'(gref) * emul   (standalone epilogue pieces for tiny tensors) */
+int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, float* dx, long n,
+               mg_stream_t stream);
+
+/* ---- fused flat Adam / AdamW (torch.optim.Adam defaults; src/gan/train_gan.py:136-145,
+ *      src/ae/train_ae.py:79).  state: double[4] = {step, beta1^step, beta2^step, unused},
+ *      advanced on device so the launch is hipGraph-replayable.  grad_scale multiplies g first
+ *      (used for 1/world_size and for clip_grad_norm_ via a device scalar if gs_dev != NULL). */
+int mg_adam_flat(float* p, const float* g, float* m, float* v, long n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay,
+                 double* state, float grad_scale, const float* gs_dev, mg_stream_t stream);
+/* out[0] = sqrt(sum g^2) ; out[1] = min(1, max_norm/(norm+1e-6))  (clip_grad_norm_, train_ae.py:121) */
+int mg_grad_norm_clip(const float* g, long n, float max_norm, float* out, void* work, size_t work_bytes,
+                      mg_stream_t stream);
+size_t mg_grad_norm_workspace_bytes(long n);
+
+/* ---- VAE extras (src/ae/model.py:127-133, src/ae/train_ae.py:35-51) ---- */
+/* z = mu + eps*exp(0.5*logvar) */
+int mg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long n, mg_stream_t stream);
+/* mse = mean((recon-x)^2); kld = -0.5*mean(1+lv-mu^2-exp(lv)); out = {total, mse, kld};
+ * drecon = 2(recon-x)/n_x ; dmu, dlv include beta-weighted KLD grads PLUS the z-path grads are added by caller */
+int mg_vae_loss(const float* recon, const float* x, long n_x, const float* mu, const float* logvar, long n_z,
+                float beta, float* out, float* drecon, float* dmu_kld, float* dlv_kld, mg_stream_t stream);
+
+/* ---- hipGraph capture of a launch sequence issued through this library (or anything else on the stream) ---- */
+int mg_graph_begin(mg_stream_t stream);
+int mg_graph_end(mg_stream_t stream, void** graph_exec_out);
+int mg_graph_launch(void* graph_exec, mg_stream_t stream);
+int mg_graph_destroy(void* graph_exec);
+
+/* ---- timing helper: HIP events on an arbitrary stream (bench.py roofline leg) ---- */
+int mg_event_create(void** ev);
+int mg_event_record(void* ev, mg_stream_t stream);
+int mg_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+int mg_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELO_GAN_HIP_H */

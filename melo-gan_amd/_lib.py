@@ -1,0 +1,94 @@
+"""ctypes binding of libmelogan_hip.so (include/melo_gan_hip.h).  Fails loudly if the library
+is absent -- there is deliberately no fallback path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmelogan_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", vp), ("scale", vp), ("shift", vp), ("zout", vp), ("act", i32),
+                ("gref", vp), ("gact", i32), ("emul", vp), ("gscale", vp), ("accumulate", i32)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
+SIGNATURES = {
+    "mg_version": (i32, []),
+    "mg_last_error": (C.c_char_p, []),
+    "mg_conv1d_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
+    "mg_conv1d_scatter2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
+    "mg_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "mg_wgrad": (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "mg_colsum_workspace_bytes": (sz, [i32]),
+    "mg_colsum": (i32, [vp, i64, i32, vp, vp, vp, sz, vp]),
+    "mg_bn_workspace_bytes": (sz, [i32]),
+    "mg_bn_train_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp, sz, vp]),
+    "mg_bn_train_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "mg_bn_eval_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, i32, vp]),
+    "mg_bn_fold": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, vp]),
+    "mg_meanT_fwd": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mg_meanT_bwd": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, vp]),
+    "mg_layernorm_fwd": (i32, [vp, vp, vp, i32, i32, vp, vp, f32, vp]),
+    "mg_layernorm_bwd_params": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "mg_dhead_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mg_dhead_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mg_dhead_wgrad": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mg_gp_interp": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+    "mg_gp_penalty": (i32, [vp, vp, vp, vp, f32, i32, i64, vp]),
+    "mg_wgan_d_loss": (i32, [vp, vp, f32, vp, i32, vp]),
+    "mg_softmax_ce": (i32, [vp, vp, vp, vp, f32, i32, i32, vp]),
+    "mg_neg_mean": (i32, [vp, vp, i32, vp]),
+    "mg_fill": (i32, [vp, f32, i64, vp]),
+    "mg_axpby": (i32, [vp, vp, f32, f32, i64, vp]),
+    "mg_copy_cols": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "mg_transpose_bcl_blc": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mg_act_bwd": (i32, [vp, vp, i32, vp, vp, i64, vp]),
+    "mg_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
+    "mg_grad_norm_workspace_bytes": (sz, [i64]),
+    "mg_grad_norm_clip": (i32, [vp, i64, f32, vp, vp, sz, vp]),
+    "mg_reparam_fwd": (i32, [vp, vp, vp, vp, i64, vp]),
+    "mg_vae_loss": (i32, [vp, vp, i64, vp, vp, i64, f32, vp, vp, vp, vp, vp]),
+    "mg_graph_begin": (i32, [vp]),
+    "mg_graph_end": (i32, [vp, C.POINTER(vp)]),
+    "mg_graph_launch": (i32, [vp, vp]),
+    "mg_graph_destroy": (i32, [vp]),
+    "mg_event_create": (i32, [C.POINTER(vp)]),
+    "mg_event_record": (i32, [vp, vp]),
+    "mg_event_elapsed_ms": (i32, [vp, vp, C.POINTER(f32)]),
+    "mg_event_destroy": (i32, [vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python melo-gan_amd/build.py` "
+            "(or __graft_entry__.build()).  There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mg_last_error()
+        raise HipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,77 @@
+// Shared helpers for libmelogan_hip (gfx950 only; no CUDA path, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include "../../include/melo_gan_hip.h"
+
+#define MG_OK 0
+#define MG_EARG (-1)
+#define MG_EUNSUP (-2)
+#define MG_EWORK (-3)
+#define MG_EHIP (-4)
+
+void mg_set_error(const char* fmt, ...);
+
+#define MG_CHECK_ARG(cond, ...)                    \
+    do {                                           \
+        if (!(cond)) {                             \
+            mg_set_error(__VA_ARGS__);             \
+            return MG_EARG;                        \
+        }                                          \
+    } while (0)
+
+#define MG_CHECK_LAUNCH(name)                                                   \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) {                                                \
+            mg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return MG_EHIP;                                                     \
+        }                                                                       \
+    } while (0)
+
+#define MG_HIP(call)                                                             \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess) {                                                 \
+            mg_set_error("%s failed: %s", #call, hipGetErrorString(e__));        \
+            return MG_EHIP;                                                      \
+        }                                                                        \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float mg_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float mg_gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float mg_act(int act, float v) {
+    switch (act) {
+        case MG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case MG_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+        case MG_ACT_GELU: return mg_gelu(v);
+        case MG_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative factor given the saved reference value (see mg_epilogue in the public header)
+__device__ __forceinline__ float mg_act_grad(int gact, float r) {
+    switch (gact) {
+        case MG_ACT_RELU: return r > 0.f ? 1.f : 0.f;
+        case MG_ACT_LRELU: return r > 0.f ? 1.f : 0.2f;
+        case MG_ACT_GELU: return mg_gelu_grad(r);
+        case MG_ACT_TANH: return 1.f - r * r;
+        default: return 1.f;
+    }
+}
+
+static inline int mg_ilog2_ceil(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+static inline long mg_cdiv(long a, long b) { return (a + b - 1) / b; }

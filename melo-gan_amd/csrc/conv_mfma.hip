@@ -1,0 +1,319 @@
+// Window-GEMM kernels for Conv1d / ConvTranspose1d / Linear on channels-last activations.
+//
+// out[m, n] = sum_{tap, c} Xwin[m, tap, c] * W(n, c, ktap)      (fp32, v_mfma_f32_32x32x2_f32)
+//
+// With a (B, T, C) layout the im2col row of output position (b, t) is a window of
+// consecutive input rows, so nothing is materialised: a workgroup stages the input rows its
+// BM output positions need (once per 16-channel chunk) into LDS and every MFMA A-operand is
+// a strided ds_read_b32 from that window.  Weights keep the reference's layouts (see the
+// public header); a 16-channel x K-tap x BN slab is transposed into LDS as [(c,k)][n].
+//
+//   gather   (Conv1d fwd, ConvT1d dgrad, Linear fwd/dgrad, stride-1 Conv1d dgrad with flip):
+//            window row of tap k for output t is t*S + k - (K-1)/2.
+//   scatter2 (ConvT1d fwd stride 2 K=5 pad 2 outpad 1, Conv1d stride-2 dgrad): the two output
+//            phases t=2u / t=2u+1 are two stride-1 correlations over taps {0,2,4} / {1,3}
+//            sharing one input window [u-1, u+1]  (SURVEY hard part 6).
+//
+// fp32 MFMA issues one 32x32x2 every 64 cycles per SIMD, i.e. the matrix pipe -- not LDS or
+// HBM -- bounds this kernel by a wide margin: 2 A + 2 B ds_read_b32 feed 4 MFMAs (256 cycles).
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+    const float* x;
+    const float* w;
+    float* y;
+    int B, Tin, Cin, Tm, Tout, N;
+    long xbs, ybs;
+    int w_sn, w_sc;
+    int flip;
+    int tt_log2;
+    int n_ttiles;
+    mg_epilogue e;
+};
+
+constexpr int BKC = 16;        // channels per LDS chunk
+constexpr int SX = BKC + 1;    // padded LDS row stride of the input window (odd => conflict-free reads)
+
+template <int S, int K, bool TR2, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, SW = BN + 1;
+    constexpr int SA = TR2 ? 1 : S;
+    constexpr int NR = TR2 ? 3 : K;
+    constexpr int NPH = TR2 ? 2 : 1;
+    constexpr int PAD = (K - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int TT = 1 << p.tt_log2;
+    const int TB = BM >> p.tt_log2;
+    const int R = (TT - 1) * SA + NR;
+    const int nrows = TB * R;
+    float* Xs = smem;
+    float* Ws = smem + ((nrows * SX + 3) & ~3);
+
+    const int mtile = blockIdx.x;
+    const int b0 = (mtile / p.n_ttiles) * TB;
+    const int t0 = (mtile % p.n_ttiles) * TT;
+    const int n0 = blockIdx.y * BN;
+    const int tin0 = TR2 ? (t0 - 1) : (t0 * S - PAD);
+
+    // per-lane operand bases
+    int abase[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int im = wm * 32 * TM + mi * 32 + (lane & 31);
+        const int seg = im >> p.tt_log2, tl = im & (TT - 1);
+        abase[mi] = (seg * R + tl * SA) * SX + (lane >> 5);
+    }
+    int bbase[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) bbase[ni] = (lane >> 5) * K * SW + wn * 32 * TN + ni * 32 + (lane & 31);
+    const int kstep = p.flip ? -SW : SW;
+    const int kbase = p.flip ? (K - 1) * SW : 0;
+
+    f32x16 acc[NPH][TM][TN];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][mi][ni][r] = 0.f;
+
+    const bool vec_ok = ((p.Cin & 3) == 0) && ((p.xbs & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
+    const bool w_nck = p.w_sc < p.w_sn;   // (c,k) contiguous for a fixed n
+
+    for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
+        __syncthreads();
+        // ---- stage the input window chunk: rows (seg, r) x 16 channels ----
+        if (vec_ok) {
+            for (int idx = tid; idx < nrows * 4; idx += 256) {
+                const int row = idx >> 2, q = idx & 3;
+                const int seg = row / R, r = row - seg * R;
+                const int b = b0 + seg, tin = tin0 + r, c = c0 + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
+                    v = *reinterpret_cast<const float4*>(p.x + (long)b * p.xbs + (long)tin * p.Cin + c);
+                float* d = Xs + row * SX + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < nrows * BKC; idx += 256) {
+                const int row = idx >> 4, cl = idx & 15;
+                const int seg = row / R, r = row - seg * R;
+                const int b = b0 + seg, tin = tin0 + r, c = c0 + cl;
+                float v = 0.f;
+                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
+                    v = p.x[(long)b * p.xbs + (long)tin * p.Cin + c];
+                Xs[row * SX + cl] = v;
+            }
+        }
+        // ---- stage the weight slab: [(c_local, k)][n] ----
+        if (w_nck) {
+            for (int e = tid; e < BN * BKC * K; e += 256) {
+                const int n = e / (BKC * K), ck = e - n * (BKC * K);
+                const int c = ck / K, k = ck - c * K;
+                float v = 0.f;
+                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
+                Ws[ck * SW + n] = v;
+            }
+        } else {
+            for (int e = tid; e < BN * BKC * K; e += 256) {
+                const int c = e / (BN * K), nk = e - c * (BN * K);
+                const int n = nk / K, k = nk - n * K;
+                float v = 0.f;
+                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
+                Ws[(c * K + k) * SW + n] = v;
+            }
+        }
+        __syncthreads();
+
+        const int crem = p.Cin - c0;
+        const int nc2 = (crem >= BKC ? BKC : crem + 1) >> 1;
+        for (int c2 = 0; c2 < nc2; ++c2) {
+            float a[NR][TM], bw[K][TN];
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) a[r][mi] = Xs[abase[mi] + r * SX + 2 * c2];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) bw[k][ni] = Ws[bbase[ni] + 2 * c2 * K * SW + kbase + k * kstep];
+            if constexpr (!TR2) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mi], bw[k][ni], acc[0][mi][ni], 0, 0, 0);
+            } else {
+                // phase 0 (t = 2u):   k=0 <- row u+1, k=2 <- row u, k=4 <- row u-1
+                // phase 1 (t = 2u+1): k=1 <- row u+1, k=3 <- row u
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[0][ni], acc[0][mi][ni], 0, 0, 0);
+                        acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[1][ni], acc[1][mi][ni], 0, 0, 0);
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[2][ni], acc[0][mi][ni], 0, 0, 0);
+                        acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[3][ni], acc[1][mi][ni], 0, 0, 0);
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][mi], bw[4][ni], acc[0][mi][ni], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    const mg_epilogue& E = p.e;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int n = n0 + wn * 32 * TN + ni * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = E.bias ? E.bias[n] : 0.f;
+        const float scale = E.scale ? E.scale[n] : 1.f;
+        const float shift = E.scale ? E.shift[n] : 0.f;
+        const float gscale = E.gscale ? E.gscale[n] : 1.f;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int im = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int seg = im >> p.tt_log2, tl = im & (TT - 1);
+                const int b = b0 + seg, t = t0 + tl;
+                if (b >= p.B || t >= p.Tm) continue;
+#pragma unroll
+                for (int ph = 0; ph < NPH; ++ph) {
+                    const int tout = TR2 ? 2 * t + ph : t;
+                    if (TR2 && tout >= p.Tout) continue;
+                    const long di = ((long)b * p.Tout + tout) * p.N + n;
+                    const long yi = (long)b * p.ybs + (long)tout * p.N + n;
+                    float v = acc[ph][mi][ni][r] + bias;
+                    v = v * scale + shift;
+                    if (E.zout) E.zout[di] = v;
+                    v = mg_act(E.act, v);
+                    if (E.gref) v *= mg_act_grad(E.gact, E.gref[di]);
+                    if (E.emul) v *= E.emul[di];
+                    v *= gscale;
+                    if (E.accumulate) v += p.y[yi];
+                    p.y[yi] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int S, int K, bool TR2, int TM, int TN>
+int launch_cfg(const ConvP& p0, hipStream_t stream) {
+    ConvP p = p0;
+    constexpr int BM = 64 * TM, BN = 64 * TN, SW = BN + 1;
+    constexpr int SA = TR2 ? 1 : S;
+    constexpr int NR = TR2 ? 3 : K;
+    int lg = mg_ilog2_ceil(p.Tm);
+    const int lgbm = mg_ilog2_ceil(BM);
+    if (lg > lgbm) lg = lgbm;
+    p.tt_log2 = lg;
+    const int TT = 1 << lg, TB = BM >> lg;
+    p.n_ttiles = (int)mg_cdiv(p.Tm, TT);
+    const int R = (TT - 1) * SA + NR;
+    const size_t lds = ((size_t)((TB * R * SX + 3) & ~3) + (size_t)BKC * K * SW) * sizeof(float);
+    if (lds > 160 * 1024) {
+        mg_set_error("conv_wgemm: LDS request %zu too large", lds);
+        return MG_EUNSUP;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgemm_kernel<S, K, TR2, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            mg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return MG_EHIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.n_ttiles * mg_cdiv(p.B, TB)), (unsigned)mg_cdiv(p.N, BN));
+    hipLaunchKernelGGL((conv_wgemm_kernel<S, K, TR2, TM, TN>), grid, dim3(256), lds, stream, p);
+    MG_CHECK_LAUNCH("conv_wgemm");
+    return MG_OK;
+}
+
+// choose the big tile when it still gives enough workgroups to cover the 256 CUs
+template <int S, int K>
+int launch_gather(const ConvP& p, hipStream_t stream) {
+    const long m_total = (long)p.B * p.Tm;
+    const long big_tiles = mg_cdiv(m_total, 128) * mg_cdiv(p.N, 128);
+    if (p.N > 64 && big_tiles >= 192) return launch_cfg<S, K, false, 2, 2>(p, stream);
+    return launch_cfg<S, K, false, 1, 1>(p, stream);
+}
+
+int fill_epilogue(ConvP& p, const mg_epilogue* epi) {
+    if (epi) {
+        p.e = *epi;
+        if (p.e.scale && !p.e.shift) {
+            mg_set_error("epilogue: scale without shift");
+            return MG_EARG;
+        }
+    } else {
+        p.e = mg_epilogue{};
+    }
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B, int Tin, int Cin, int N, int K,
+                                int stride, int flip, int w_sn, int w_sc, long xbs, long ybs,
+                                const mg_epilogue* epi, mg_stream_t stream) {
+    MG_CHECK_ARG(x && w && y, "mg_conv1d_gather: null tensor");
+    MG_CHECK_ARG(B > 0 && Tin > 0 && Cin > 0 && N > 0, "mg_conv1d_gather: bad shape B=%d Tin=%d Cin=%d N=%d", B, Tin, Cin, N);
+    MG_CHECK_ARG(K == 1 || K == 3 || K == 5, "mg_conv1d_gather: K=%d unsupported", K);
+    MG_CHECK_ARG(stride == 1 || stride == 2, "mg_conv1d_gather: stride=%d unsupported", stride);
+    MG_CHECK_ARG(!(flip && stride != 1), "mg_conv1d_gather: flip requires stride 1");
+    MG_CHECK_ARG(w_sn > 0 && w_sc > 0, "mg_conv1d_gather: bad weight strides");
+    const int pad = (K - 1) / 2;
+    const int Tout = (Tin + 2 * pad - K) / stride + 1;
+    MG_CHECK_ARG(Tout > 0, "mg_conv1d_gather: Tout=%d", Tout);
+    ConvP p{};
+    p.x = x; p.w = w; p.y = y;
+    p.B = B; p.Tin = Tin; p.Cin = Cin; p.Tm = Tout; p.Tout = Tout; p.N = N;
+    p.xbs = xbs ? xbs : (long)Tin * Cin;
+    p.ybs = ybs ? ybs : (long)Tout * N;
+    p.w_sn = w_sn; p.w_sc = w_sc; p.flip = flip;
+    if (int rc = fill_epilogue(p, epi)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (stride == 1) {
+        if (K == 1) return launch_gather<1, 1>(p, s);
+        if (K == 3) return launch_gather<1, 3>(p, s);
+        return launch_gather<1, 5>(p, s);
+    }
+    if (K == 5) return launch_gather<2, 5>(p, s);
+    mg_set_error("mg_conv1d_gather: stride 2 needs K=5");
+    return MG_EUNSUP;
+}
+
+extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int B, int Tin, int Cin, int N,
+                                  int Tout, int w_sn, int w_sc, long xbs, long ybs, const mg_epilogue* epi,
+                                  mg_stream_t stream) {
+    MG_CHECK_ARG(x && w && y, "mg_conv1d_scatter2: null tensor");
+    MG_CHECK_ARG(B > 0 && Tin > 0 && Cin > 0 && N > 0, "mg_conv1d_scatter2: bad shape");
+    MG_CHECK_ARG(Tout == 2 * Tin || Tout == 2 * Tin - 1, "mg_conv1d_scatter2: Tout=%d must be 2*Tin or 2*Tin-1", Tout);
+    ConvP p{};
+    p.x = x; p.w = w; p.y = y;
+    p.B = B; p.Tin = Tin; p.Cin = Cin; p.Tm = Tin; p.Tout = Tout; p.N = N;
+    p.xbs = xbs ? xbs : (long)Tin * Cin;
+    p.ybs = ybs ? ybs : (long)p.Tout * N;
+    p.w_sn = w_sn; p.w_sc = w_sc; p.flip = 0;
+    if (int rc = fill_epilogue(p, epi)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long m_total = (long)B * Tin;
+    const long big_tiles = mg_cdiv(m_total, 64) * mg_cdiv(N, 128);
+    if (N > 64 && big_tiles >= 192) return launch_cfg<2, 5, true, 1, 2>(p, s);
+    return launch_cfg<2, 5, true, 1, 1>(p, s);
+}

@@ -1,0 +1,763 @@
+// HBM-bound streaming kernels around the window GEMMs: per-channel reductions, BatchNorm
+// (train fwd/bwd, eval), pooling, LayerNorm(6), the critic head, WGAN-GP pieces, losses,
+// flat Adam.  All fp32, channels-last; rows are (b, t), columns are channels, so a wave's
+// 64 lanes read 64 consecutive channels (256 B) of one row -- coalesced by construction.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_SPLITS = 128;  // max row slices for two-stage column reductions
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of one float per thread (blockDim.x multiple of 64, <= 1024)
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}
+
+// ---------------- column sums: partial[split][{sum,sumsq}][c] ----------------
+// MODE 0: v = x          MODE 1 (BN backward): v1 = dy*mask(a), v2 = v1 * xhat(z)
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                             const float* __restrict__ z,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int act, long R,
+                                                             int C, long rows_per, float* __restrict__ part,
+                                                             int want_sq) {
+    __shared__ float sh[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long r0 = (long)blockIdx.y * rows_per;
+    long r1 = r0 + rows_per;
+    if (r1 > R) r1 = R;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        float mu = 0.f, is = 0.f;
+        if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+        for (long r = r0 + ry; r < r1; r += 4) {
+            const long i = r * C + c;
+            if (MODE == 0) {
+                const float v = x[i];
+                s1 += v;
+                s2 += v * v;
+            } else {
+                const float dy = x[i] * mg_act_grad(act, a[i]);
+                s1 += dy;
+                s2 += dy * (z[i] - mu) * is;
+            }
+        }
+    }
+    sh[0][ry][cx] = s1;
+    sh[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const float t1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+        const float t2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+        part[((long)blockIdx.y * 2 + 0) * C + c] = t1;
+        if (want_sq) part[((long)blockIdx.y * 2 + 1) * C + c] = t2;
+    }
+}
+
+struct RedPlan { int nsplit; long rows_per; };
+RedPlan red_plan(long R) {
+    RedPlan p;
+    long ns = mg_cdiv(R, 64);
+    if (ns > RED_SPLITS) ns = RED_SPLITS;
+    if (ns < 1) ns = 1;
+    p.rows_per = mg_cdiv(R, ns);
+    p.nsplit = (int)mg_cdiv(R, p.rows_per);
+    return p;
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nsplit, int C, float* sum, float* sumsq) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nsplit; ++k) {
+        s1 += part[((long)k * 2) * C + c];
+        if (sumsq) s2 += part[((long)k * 2 + 1) * C + c];
+    }
+    sum[c] = (float)s1;
+    if (sumsq) sumsq[c] = (float)s2;
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nsplit, int C, long R, float momentum,
+                                      float eps, float* running_mean, float* running_var, float* save_mean,
+                                      float* save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nsplit; ++k) {
+        s1 += part[((long)k * 2) * C + c];
+        s2 += part[((long)k * 2 + 1) * C + c];
+    }
+    const double mean = s1 / (double)R;
+    double var = s2 / (double)R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ z, float* __restrict__ a, long n, int C,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ mean, const float* __restrict__ invstd, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    a[i] = mg_act(act, v);
+}
+
+__global__ void bn_eval_kernel(const float* __restrict__ z, float* __restrict__ a, long n, int C,
+                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const float v = (z[i] - rm[c]) / sqrtf(rv[c] + eps) * gamma[c] + beta[c];
+    a[i] = mg_act(act, v);
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                               const float* cb, float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] + ((cb ? cb[c] : 0.f) - rm[c]) * s;
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nsplit, int C, float* dgamma, float* dbeta,
+                                    float* sums /* [2][C] */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nsplit; ++k) {
+        s1 += part[((long)k * 2) * C + c];
+        s2 += part[((long)k * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    sums[c] = (float)s1;
+    sums[C + c] = (float)s2;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ a,
+                                    const float* __restrict__ z, float* __restrict__ dz, long n, int C, long R,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ sums, int act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const float dy = da[i] * mg_act_grad(act, a[i]);
+    const float xh = (z[i] - mean[c]) * invstd[c];
+    const float invR = 1.f / (float)R;
+    dz[i] = gamma[c] * invstd[c] * (dy - sums[c] * invR - xh * sums[C + c] * invR);
+}
+
+// ---------------- mean over time ----------------
+__global__ void meanT_fwd_kernel(const float* __restrict__ a, float* __restrict__ h, int T, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ry = threadIdx.x >> 6;
+    __shared__ float sh[4][64];
+    float s = 0.f;
+    if (c < C)
+        for (int t = ry; t < T; t += 4) s += a[((long)b * T + t) * C + c];
+    sh[ry][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const int cx = threadIdx.x & 63;
+        h[(long)b * C + c] = (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) / (float)T;
+    }
+}
+
+__global__ void meanT_bwd_kernel(const float* __restrict__ dh, float* __restrict__ dz, long n, int T, int C,
+                                 const float* __restrict__ gref, int gact, const float* __restrict__ gscale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const long b = i / ((long)T * C);
+    float v = dh[b * C + c] / (float)T;
+    if (gref) v *= mg_act_grad(gact, gref[i]);
+    if (gscale) v *= gscale[c];
+    dz[i] = v;
+}
+
+// ---------------- LayerNorm (small D) ----------------
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ xhat,
+                                     int B, int D, const float* gamma, const float* beta, float eps) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float mean = 0.f;
+    for (int j = 0; j < D; ++j) mean += x[(long)b * D + j];
+    mean /= (float)D;
+    float var = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float d = x[(long)b * D + j] - mean;
+        var += d * d;
+    }
+    var /= (float)D;
+    const float is = 1.f / sqrtf(var + eps);
+    for (int j = 0; j < D; ++j) {
+        const float xh = (x[(long)b * D + j] - mean) * is;
+        if (xhat) xhat[(long)b * D + j] = xh;
+        y[(long)b * D + j] = xh * gamma[j] + beta[j];
+    }
+}
+
+__global__ void layernorm_bwd_params_kernel(const float* dy, const float* xhat, float* dgamma, float* dbeta, int B,
+                                            int D) {
+    const int j = threadIdx.x;
+    if (j >= D) return;
+    float g = 0.f, bsum = 0.f;
+    for (int b = 0; b < B; ++b) {
+        g += dy[(long)b * D + j] * xhat[(long)b * D + j];
+        bsum += dy[(long)b * D + j];
+    }
+    dgamma[j] = g;
+    dbeta[j] = bsum;
+}
+
+// ---------------- critic head ----------------
+__global__ void dhead_fwd_kernel(const float* __restrict__ f, const float* __restrict__ emb,
+                                 const float* __restrict__ w, const float* __restrict__ bias, float* s, int Be,
+                                 int F, int E) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int j = lane; j < F; j += 64) acc += f[(long)b * F + j] * w[j];
+    if (emb)
+        for (int j = lane; j < E; j += 64) acc += emb[(long)(b % Be) * E + j] * w[F + j];
+    acc = wave_sum(acc);
+    if (lane == 0) s[b] = acc + bias[0];
+}
+
+__global__ void dhead_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ f,
+                                 const float* __restrict__ w, float* dU, int B, int F) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * F) return;
+    const int b = (int)(i / F), j = (int)(i % F);
+    dU[i] = ds[b] * w[j] * (f[i] > 0.f ? 1.f : 0.2f);
+}
+
+__global__ void dhead_demb_kernel(const float* __restrict__ ds, const float* __restrict__ w, float* demb, int Be,
+                                  int F, int E, int nb_emb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Be * E) return;
+    const int be = (int)(i / E), j = (int)(i % E);
+    float s = 0.f;
+    for (int b = be; b < nb_emb; b += Be) s += ds[b];
+    demb[i] = s * w[F + j];
+}
+
+__global__ void dhead_wgrad_kernel(const float* __restrict__ ds, const float* __restrict__ f,
+                                   const float* __restrict__ emb, const float* __restrict__ gf, float* dw,
+                                   float* dbias, int nb, int ng, int Be, int F, int E) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < F) {
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += ds[b] * f[(long)b * F + j];
+        float g = 0.f;
+        if (gf)
+            for (int b = 0; b < ng; ++b) g += gf[(long)b * F + j];
+        dw[j] = s + g;
+    } else if (j < F + E) {
+        float s = 0.f;
+        if (emb)
+            for (int b = 0; b < nb; ++b) s += ds[b] * emb[(long)(b % Be) * E + (j - F)];
+        dw[j] = s;
+    } else if (j == F + E) {
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += ds[b];
+        dbias[0] = s;
+    }
+}
+
+// ---------------- WGAN-GP ----------------
+__global__ void gp_interp_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                 const float* __restrict__ alpha, float* __restrict__ xhat, long n, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float a = alpha[i / n];
+    xhat[i] = a * real[i] + (1.f - a) * fake[i];
+}
+
+__global__ __launch_bounds__(1024) void gp_norm_kernel(const float* __restrict__ g, float* __restrict__ gbar,
+                                                       float* norms, float coef, int B, long n) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x;
+    const float* gb = g + (long)b * n;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += gb[i] * gb[i];
+    s = block_sum(s, sh);
+    const float nrm = sqrtf(s);
+    if (threadIdx.x == 0) norms[b] = nrm;
+    if (gbar) {
+        const float fac = nrm > 0.f ? coef * (2.f / (float)B) * (nrm - 1.f) / nrm : 0.f;
+        float* ob = gbar + (long)b * n;
+        for (long i = threadIdx.x; i < n; i += blockDim.x) ob[i] = fac * gb[i];
+    }
+}
+
+__global__ void gp_final_kernel(const float* norms, float* gp, int B) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float d = norms[b] - 1.f;
+        s += d * d;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) gp[0] = s / (float)B;
+}
+
+// ---------------- losses ----------------
+__global__ void wgan_d_loss_kernel(const float* s, const float* gp, float lambda_gp, float* out, int nb) {
+    __shared__ float sh[16];
+    float r = 0.f, f = 0.f;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        r += s[b];
+        f += s[nb + b];
+    }
+    r = block_sum(r, sh);
+    f = block_sum(f, sh);
+    if (threadIdx.x == 0) {
+        const float mr = r / (float)nb, mf = f / (float)nb;
+        out[0] = mf - mr + lambda_gp * gp[0];
+        out[1] = mr;
+        out[2] = mf;
+    }
+}
+
+__global__ void neg_mean_kernel(const float* s, float* out, int B) {
+    __shared__ float sh[16];
+    float r = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) r += s[b];
+    r = block_sum(r, sh);
+    if (threadIdx.x == 0) out[0] = -r / (float)B;
+}
+
+__global__ void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, float* loss,
+                                  float* dlogits, float coef, int B, int C) {
+    __shared__ float sh[16];
+    float l = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* z = logits + (long)b * C;
+        float mx = z[0];
+        for (int j = 1; j < C; ++j) mx = fmaxf(mx, z[j]);
+        float se = 0.f;
+        for (int j = 0; j < C; ++j) se += expf(z[j] - mx);
+        const float lse = mx + logf(se);
+        const int y = (int)target[b];
+        l += lse - z[y];
+        if (dlogits)
+            for (int j = 0; j < C; ++j)
+                dlogits[(long)b * C + j] = coef * (expf(z[j] - lse) - (j == y ? 1.f : 0.f)) / (float)B;
+    }
+    l = block_sum(l, sh);
+    if (threadIdx.x == 0) loss[0] = l / (float)B;
+}
+
+// ---------------- elementwise ----------------
+__global__ void fill_kernel(float* x, float v, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, float a, float b, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+__global__ void copy_cols_kernel(const float* __restrict__ src, int sld, int soff, float* __restrict__ dst, int dld,
+                                 int doff, int rows, int ncols, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * ncols) return;
+    const int r = (int)(i / ncols), j = (int)(i % ncols);
+    const float v = src[(long)r * sld + soff + j];
+    float* d = dst + (long)r * dld + doff + j;
+    *d = accumulate ? *d + v : v;
+}
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int L) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, l = l0 + tx;
+        tile[r][tx] = (c < C && l < L) ? in[((long)b * C + c) * L + l] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int l = l0 + r, c = c0 + tx;
+        if (l < L && c < C) out[((long)b * L + l) * C + c] = tile[tx][r];
+    }
+}
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gref, int gact,
+                               const float* __restrict__ emul, float* __restrict__ dx, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = dy[i];
+    if (gref) v *= mg_act_grad(gact, gref[i]);
+    if (emul) v *= emul[i];
+    dx[i] = v;
+}
+
+// ---------------- Adam ----------------
+__global__ void adam_advance_kernel(double* state, double beta1, double beta2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (state[0] == 0.0) { state[1] = 1.0; state[2] = 1.0; }
+        state[0] += 1.0;
+        state[1] *= beta1;
+        state[2] *= beta2;
+    }
+}
+__global__ void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                                  float wd, const double* __restrict__ state, float grad_scale,
+                                  const float* __restrict__ gs_dev) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double bc1 = 1.0 - state[1];
+    const double bc2 = 1.0 - state[2];
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    float gs = grad_scale;
+    if (gs_dev) gs *= gs_dev[0];
+    const float gi = g[i] * gs;
+    float pi = p[i];
+    if (wd != 0.f) pi *= (1.f - lr * wd);  // decoupled (AdamW)
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+}
+
+__global__ __launch_bounds__(1024) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* part) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        s += g[i] * g[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void norm_clip_final_kernel(const float* part, int nparts, float max_norm, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nparts; ++i) s += part[i];
+        const float nrm = (float)sqrt(s);
+        out[0] = nrm;
+        const float c = max_norm / (nrm + 1e-6f);
+        out[1] = c < 1.f ? c : 1.f;
+    }
+}
+
+// ---------------- VAE ----------------
+__global__ void reparam_kernel(const float* mu, const float* lv, const float* eps, float* z, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = mu[i] + eps[i] * expf(0.5f * lv[i]);
+}
+__global__ __launch_bounds__(1024) void vae_loss_kernel(const float* __restrict__ recon, const float* __restrict__ x,
+                                                        long n_x, const float* __restrict__ mu,
+                                                        const float* __restrict__ lv, long n_z, float beta,
+                                                        float* out, float* drecon, float* dmu, float* dlv) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n_x; i += blockDim.x) {
+        const float d = recon[i] - x[i];
+        s += d * d;
+        if (drecon) drecon[i] = 2.f * d / (float)n_x;
+    }
+    s = block_sum(s, sh);
+    float k = 0.f;
+    for (long i = threadIdx.x; i < n_z; i += blockDim.x) {
+        const float e = expf(lv[i]);
+        k += 1.f + lv[i] - mu[i] * mu[i] - e;
+        if (dmu) dmu[i] = beta * mu[i] / (float)n_z;
+        if (dlv) dlv[i] = beta * (-0.5f) * (1.f - e) / (float)n_z;
+    }
+    k = block_sum(k, sh);
+    if (threadIdx.x == 0) {
+        const float mse = s / (float)n_x, kld = -0.5f * k / (float)n_z;
+        out[0] = mse + beta * kld;
+        out[1] = mse;
+        out[2] = kld;
+    }
+}
+
+inline unsigned nblk(long n, int bs = 256) { return (unsigned)mg_cdiv(n, bs); }
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+size_t mg_colsum_workspace_bytes(int C) { return (size_t)RED_SPLITS * 2 * (size_t)C * sizeof(float) + 2 * (size_t)C * sizeof(float); }
+size_t mg_bn_workspace_bytes(int C) { return mg_colsum_workspace_bytes(C); }
+
+int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq, void* work, size_t work_bytes,
+              mg_stream_t stream) {
+    MG_CHECK_ARG(x && sum && R > 0 && C > 0, "mg_colsum: bad args");
+    if (!work || work_bytes < mg_colsum_workspace_bytes(C)) { mg_set_error("mg_colsum: workspace too small"); return MG_EWORK; }
+    const RedPlan pl = red_plan(R);
+    dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
+    hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, x, nullptr, nullptr, nullptr, nullptr, 0, R, C,
+                       pl.rows_per, (float*)work, sumsq ? 1 : 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const float*)work, pl.nsplit, C, sum, sumsq);
+    MG_CHECK_LAUNCH("colsum");
+    return MG_OK;
+}
+
+int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                    float* save_invstd, int act, void* work, size_t work_bytes, mg_stream_t stream) {
+    MG_CHECK_ARG(z && a && gamma && beta && save_mean && save_invstd && R > 0 && C > 0, "mg_bn_train_fwd: bad args");
+    MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "mg_bn_train_fwd: running stats must come in pairs");
+    if (!work || work_bytes < mg_bn_workspace_bytes(C)) { mg_set_error("mg_bn_train_fwd: workspace too small"); return MG_EWORK; }
+    const RedPlan pl = red_plan(R);
+    dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
+    hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, z, nullptr, nullptr, nullptr, nullptr, 0, R, C,
+                       pl.rows_per, (float*)work, 1);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const float*)work, pl.nsplit, C, R,
+                       momentum, eps, running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, z, a, R * C, C, gamma, beta, save_mean,
+                       save_invstd, act);
+    MG_CHECK_LAUNCH("bn_train_fwd");
+    return MG_OK;
+}
+
+int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, long R, int C, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int act,
+                    void* work, size_t work_bytes, mg_stream_t stream) {
+    MG_CHECK_ARG(da && a && z && dz && gamma && save_mean && save_invstd && dgamma && dbeta, "mg_bn_train_bwd: bad args");
+    if (!work || work_bytes < mg_bn_workspace_bytes(C)) { mg_set_error("mg_bn_train_bwd: workspace too small"); return MG_EWORK; }
+    const RedPlan pl = red_plan(R);
+    float* part = (float*)work;
+    float* sums = part + (size_t)RED_SPLITS * 2 * C;
+    dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), 0, ST, da, a, z, save_mean, save_invstd, act, R, C,
+                       pl.rows_per, part, 1);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const float*)part, pl.nsplit, C, dgamma,
+                       dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, da, a, z, dz, R * C, C, R, gamma,
+                       save_mean, save_invstd, (const float*)sums, act);
+    MG_CHECK_LAUNCH("bn_train_bwd");
+    return MG_OK;
+}
+
+int mg_bn_eval_fwd(const float* z, float* a, long R, int C, const float* gamma, const float* beta,
+                   const float* running_mean, const float* running_var, float eps, int act, mg_stream_t stream) {
+    MG_CHECK_ARG(z && a && gamma && beta && running_mean && running_var, "mg_bn_eval_fwd: bad args");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, z, a, R * C, C, gamma, beta, running_mean,
+                       running_var, eps, act);
+    MG_CHECK_LAUNCH("bn_eval_fwd");
+    return MG_OK;
+}
+
+int mg_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+               const float* conv_bias, float eps, float* scale, float* shift, int C, mg_stream_t stream) {
+    MG_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift, "mg_bn_fold: bad args");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(nblk(C)), dim3(256), 0, ST, gamma, beta, running_mean, running_var,
+                       conv_bias, eps, scale, shift, C);
+    MG_CHECK_LAUNCH("bn_fold");
+    return MG_OK;
+}
+
+int mg_meanT_fwd(const float* a, float* h, int B, int T, int C, mg_stream_t stream) {
+    MG_CHECK_ARG(a && h && B > 0 && T > 0 && C > 0, "mg_meanT_fwd: bad args");
+    hipLaunchKernelGGL(meanT_fwd_kernel, dim3((unsigned)mg_cdiv(C, 64), (unsigned)B), dim3(256), 0, ST, a, h, T, C);
+    MG_CHECK_LAUNCH("meanT_fwd");
+    return MG_OK;
+}
+
+int mg_meanT_bwd(const float* dh, float* dz, int B, int T, int C, const float* gref, int gact, const float* gscale,
+                 mg_stream_t stream) {
+    MG_CHECK_ARG(dh && dz && B > 0 && T > 0 && C > 0, "mg_meanT_bwd: bad args");
+    const long n = (long)B * T * C;
+    hipLaunchKernelGGL(meanT_bwd_kernel, dim3(nblk(n)), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale);
+    MG_CHECK_LAUNCH("meanT_bwd");
+    return MG_OK;
+}
+
+int mg_layernorm_fwd(const float* x, float* y, float* xhat, int B, int D, const float* gamma, const float* beta,
+                     float eps, mg_stream_t stream) {
+    MG_CHECK_ARG(x && y && gamma && beta && B > 0 && D > 0 && D <= 64, "mg_layernorm_fwd: bad args (D<=64)");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(nblk(B, 64)), dim3(64), 0, ST, x, y, xhat, B, D, gamma, beta, eps);
+    MG_CHECK_LAUNCH("layernorm_fwd");
+    return MG_OK;
+}
+
+int mg_layernorm_bwd_params(const float* dy, const float* xhat, float* dgamma, float* dbeta, int B, int D,
+                            mg_stream_t stream) {
+    MG_CHECK_ARG(dy && xhat && dgamma && dbeta && D <= 64, "mg_layernorm_bwd_params: bad args");
+    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(1), dim3(64), 0, ST, dy, xhat, dgamma, dbeta, B, D);
+    MG_CHECK_LAUNCH("layernorm_bwd_params");
+    return MG_OK;
+}
+
+int mg_dhead_fwd(const float* f, const float* emb, const float* w, const float* bias, float* s, int B, int Be,
+                 int F, int E, mg_stream_t stream) {
+    MG_CHECK_ARG(f && w && bias && s && B > 0 && F > 0, "mg_dhead_fwd: bad args");
+    MG_CHECK_ARG(!emb || (Be > 0 && E > 0), "mg_dhead_fwd: bad emb shape");
+    hipLaunchKernelGGL(dhead_fwd_kernel, dim3(B), dim3(64), 0, ST, f, emb, w, bias, s, Be > 0 ? Be : 1, F, emb ? E : 0);
+    MG_CHECK_LAUNCH("dhead_fwd");
+    return MG_OK;
+}
+
+int mg_dhead_bwd(const float* ds, const float* f, const float* w, float* dU, float* demb, int B, int Be, int F,
+                 int E, int nb_emb, mg_stream_t stream) {
+    MG_CHECK_ARG(ds && f && w && dU, "mg_dhead_bwd: bad args");
+    hipLaunchKernelGGL(dhead_bwd_kernel, dim3(nblk((long)B * F)), dim3(256), 0, ST, ds, f, w, dU, B, F);
+    if (demb)
+        hipLaunchKernelGGL(dhead_demb_kernel, dim3(nblk((long)Be * E)), dim3(256), 0, ST, ds, w, demb, Be, F, E, nb_emb);
+    MG_CHECK_LAUNCH("dhead_bwd");
+    return MG_OK;
+}
+
+int mg_dhead_wgrad(const float* ds, const float* f, const float* emb, const float* gf, float* dw, float* dbias,
+                   int nb, int ng, int Be, int F, int E, mg_stream_t stream) {
+    MG_CHECK_ARG(ds && f && dw && dbias, "mg_dhead_wgrad: bad args");
+    hipLaunchKernelGGL(dhead_wgrad_kernel, dim3(nblk(F + E + 1, 64)), dim3(64), 0, ST, ds, f, emb, gf, dw, dbias, nb, ng,
+                       Be > 0 ? Be : 1, F, emb ? E : 0);
+    MG_CHECK_LAUNCH("dhead_wgrad");
+    return MG_OK;
+}
+
+int mg_gp_interp(const float* real, const float* fake, const float* alpha, float* xhat, int B, long n,
+                 mg_stream_t stream) {
+    MG_CHECK_ARG(real && fake && alpha && xhat && B > 0 && n > 0, "mg_gp_interp: bad args");
+    hipLaunchKernelGGL(gp_interp_kernel, dim3(nblk(B * n)), dim3(256), 0, ST, real, fake, alpha, xhat, n, B * n);
+    MG_CHECK_LAUNCH("gp_interp");
+    return MG_OK;
+}
+
+int mg_gp_penalty(const float* g, float* gbar, float* norms, float* gp, float coef, int B, long n,
+                  mg_stream_t stream) {
+    MG_CHECK_ARG(g && norms && gp && B > 0 && n > 0, "mg_gp_penalty: bad args");
+    hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(1024), 0, ST, g, gbar, norms, coef, B, n);
+    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(256), 0, ST, (const float*)norms, gp, B);
+    MG_CHECK_LAUNCH("gp_penalty");
+    return MG_OK;
+}
+
+int mg_wgan_d_loss(const float* s, const float* gp, float lambda_gp, float* out, int nb, mg_stream_t stream) {
+    MG_CHECK_ARG(s && gp && out && nb > 0, "mg_wgan_d_loss: bad args");
+    hipLaunchKernelGGL(wgan_d_loss_kernel, dim3(1), dim3(256), 0, ST, s, gp, lambda_gp, out, nb);
+    MG_CHECK_LAUNCH("wgan_d_loss");
+    return MG_OK;
+}
+
+int mg_softmax_ce(const float* logits, const int64_t* target, float* loss, float* dlogits, float coef, int B, int C,
+                  mg_stream_t stream) {
+    MG_CHECK_ARG(logits && target && loss && B > 0 && C > 0 && C <= 32, "mg_softmax_ce: bad args");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, ST, logits, target, loss, dlogits, coef, B, C);
+    MG_CHECK_LAUNCH("softmax_ce");
+    return MG_OK;
+}
+
+int mg_neg_mean(const float* s, float* out, int B, mg_stream_t stream) {
+    MG_CHECK_ARG(s && out && B > 0, "mg_neg_mean: bad args");
+    hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(256), 0, ST, s, out, B);
+    MG_CHECK_LAUNCH("neg_mean");
+    return MG_OK;
+}
+
+int mg_fill(float* x, float v, long n, mg_stream_t stream) {
+    MG_CHECK_ARG(x && n >= 0, "mg_fill: bad args");
+    if (n == 0) return MG_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(nblk(n)), dim3(256), 0, ST, x, v, n);
+    MG_CHECK_LAUNCH("fill");
+    return MG_OK;
+}
+
+int mg_axpby(const float* x, float* y, float a, float b, long n, mg_stream_t stream) {
+    MG_CHECK_ARG(x && y && n > 0, "mg_axpby: bad args");
+    hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n)), dim3(256), 0, ST, x, y, a, b, n);
+    MG_CHECK_LAUNCH("axpby");
+    return MG_OK;
+}
+
+int mg_copy_cols(const float* src, int sld, int soff, float* dst, int dld, int doff, int rows, int ncols,
+                 int accumulate, mg_stream_t stream) {
+    MG_CHECK_ARG(src && dst && rows > 0 && ncols > 0 && soff + ncols <= sld && doff + ncols <= dld, "mg_copy_cols: bad args");
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(nblk((long)rows * ncols)), dim3(256), 0, ST, src, sld, soff, dst, dld, doff,
+                       rows, ncols, accumulate);
+    MG_CHECK_LAUNCH("copy_cols");
+    return MG_OK;
+}
+
+int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, mg_stream_t stream) {
+    MG_CHECK_ARG(in && out && B > 0 && C > 0 && L > 0, "mg_transpose_bcl_blc: bad args");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)mg_cdiv(L, 32), (unsigned)mg_cdiv(C, 32), (unsigned)B), dim3(256),
+                       0, ST, in, out, C, L);
+    MG_CHECK_LAUNCH("transpose");
+    return MG_OK;
+}
+
+int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, float* dx, long n,
+               mg_stream_t stream) {
+    MG_CHECK_ARG(dy && dx && n > 0, "mg_act_bwd: bad args");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(n)), dim3(256), 0, ST, dy, gref, gact, emul, dx, n);
+    MG_CHECK_LAUNCH("act_bwd");
+    return MG_OK;
+}
+
+int mg_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, double* state, float grad_scale, const float* gs_dev,
+                 mg_stream_t stream) {
+    MG_CHECK_ARG(p && g && m && v && state && n > 0, "mg_adam_flat: bad args");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST, state, (double)beta1, (double)beta2);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (const double*)state, grad_scale, gs_dev);
+    MG_CHECK_LAUNCH("adam_flat");
+    return MG_OK;
+}
+
+size_t mg_grad_norm_workspace_bytes(long n) { return 1024 * sizeof(float); }
+
+int mg_grad_norm_clip(const float* g, long n, float max_norm, float* out, void* work, size_t work_bytes,
+                      mg_stream_t stream) {
+    MG_CHECK_ARG(g && out && n > 0, "mg_grad_norm_clip: bad args");
+    if (!work || work_bytes < mg_grad_norm_workspace_bytes(n)) { mg_set_error("mg_grad_norm_clip: workspace too small"); return MG_EWORK; }
+    int nparts = (int)mg_cdiv(n, 1024 * 8);
+    if (nparts > 1024) nparts = 1024;
+    if (nparts < 1) nparts = 1;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nparts), dim3(1024), 0, ST, g, n, (float*)work);
+    hipLaunchKernelGGL(norm_clip_final_kernel, dim3(1), dim3(64), 0, ST, (const float*)work, nparts, max_norm, out);
+    MG_CHECK_LAUNCH("grad_norm_clip");
+    return MG_OK;
+}
+
+int mg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long n, mg_stream_t stream) {
+    MG_CHECK_ARG(mu && logvar && eps && z && n > 0, "mg_reparam_fwd: bad args");
+    hipLaunchKernelGGL(reparam_kernel, dim3(nblk(n)), dim3(256), 0, ST, mu, logvar, eps, z, n);
+    MG_CHECK_LAUNCH("reparam");
+    return MG_OK;
+}
+
+int mg_vae_loss(const float* recon, const float* x, long n_x, const float* mu, const float* logvar, long n_z,
+                float beta, float* out, float* drecon, float* dmu_kld, float* dlv_kld, mg_stream_t stream) {
+    MG_CHECK_ARG(recon && x && mu && logvar && out && n_x > 0 && n_z > 0, "mg_vae_loss: bad args");
+    hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(1024), 0, ST, recon, x, n_x, mu, logvar, n_z, beta, out, drecon,
+                       dmu_kld, dlv_kld);
+    MG_CHECK_LAUNCH("vae_loss");
+    return MG_OK;
+}
+
+}  // extern "C"

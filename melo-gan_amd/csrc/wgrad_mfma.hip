@@ -1,0 +1,223 @@
+// Weight-gradient kernel (fp32 MFMA) for Conv1d / ConvTranspose1d / Linear on channels-last
+// activations:
+//
+//   out[a][b][k] = sum_{segments, batch, u}  S[batch, u, a] * L[batch, u*stride + k - (K-1)/2, b]
+//
+// i.e. for every tap k a GEMM  Out_k = S^T (A x r) * L_k (r x Bc)  whose reduction index r runs
+// over (batch, time).  A workgroup owns a 64(a) x 64(b) x K output tile and one slice of the
+// batches; per 32-row r-chunk it stages S rows and the L window in LDS, and each wave keeps
+// K accumulators (32x32 per tap).  Slices write partial slabs; mg_wgrad's second kernel sums
+// them in a fixed order, so the result is bitwise reproducible (no float atomics).
+#include "common.h"
+
+namespace {
+
+struct WgradP {
+    const float* s[2];
+    const float* l[2];
+    int nb[2];
+    float* part;
+    int Ts, Tl, A, Bc;
+    int tt_log2, n_ttiles;
+    int bps;        // batch groups per split
+    int n_bgroups;  // total batch groups (over both segments)
+    int nbg0;       // batch groups in segment 0
+    long slab;      // A*Bc*K
+};
+
+constexpr int RT = 32;   // reduction rows per LDS chunk
+constexpr int BA = 64, BB = 64;
+
+template <int S, int K>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
+    constexpr int PAD = (K - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int TT = 1 << p.tt_log2, TB = RT >> p.tt_log2;
+    const int R = (TT - 1) * S + K;
+    float* Ss = smem;                 // [RT][BA]
+    float* Ls = smem + RT * BA;       // [TB*R][BB]
+    const int a0 = blockIdx.x * BA, b0 = blockIdx.y * BB;
+    const int split = blockIdx.z;
+
+    f32x16 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    const int h = lane >> 5;
+    const int g_begin = split * p.bps;
+    const int g_end = min(g_begin + p.bps, p.n_bgroups);
+    const bool vecS = ((p.A & 3) == 0) && ((((uintptr_t)p.s[0]) & 15) == 0) && (p.nb[1] == 0 || (((uintptr_t)p.s[1]) & 15) == 0);
+    const bool vecL = ((p.Bc & 3) == 0) && ((((uintptr_t)p.l[0]) & 15) == 0) && (p.nb[1] == 0 || (((uintptr_t)p.l[1]) & 15) == 0);
+
+    for (int g = g_begin; g < g_end; ++g) {
+        const int seg_id = g < p.nbg0 ? 0 : 1;
+        const int bg = seg_id ? g - p.nbg0 : g;
+        const float* Sp = p.s[seg_id];
+        const float* Lp = p.l[seg_id];
+        const int nb = p.nb[seg_id];
+        const int bb0 = bg * TB;
+        for (int tt = 0; tt < p.n_ttiles; ++tt) {
+            const int t0 = tt * TT;
+            const int tl0 = t0 * S - PAD;
+            __syncthreads();
+            // S rows: (seg, tl) -> r = seg*TT + tl
+            if (vecS) {
+                for (int idx = tid; idx < RT * (BA / 4); idx += 256) {
+                    const int r = idx / (BA / 4), q = idx - r * (BA / 4);
+                    const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+                    const int b = bb0 + seg, t = t0 + tl, a = a0 + 4 * q;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (b < nb && t < p.Ts && a < p.A)
+                        v = *reinterpret_cast<const float4*>(Sp + ((long)b * p.Ts + t) * p.A + a);
+                    *reinterpret_cast<float4*>(Ss + r * BA + 4 * q) = v;
+                }
+            } else {
+                for (int idx = tid; idx < RT * BA; idx += 256) {
+                    const int r = idx / BA, al = idx - r * BA;
+                    const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+                    const int b = bb0 + seg, t = t0 + tl, a = a0 + al;
+                    float v = 0.f;
+                    if (b < nb && t < p.Ts && a < p.A) v = Sp[((long)b * p.Ts + t) * p.A + a];
+                    Ss[r * BA + al] = v;
+                }
+            }
+            // L window rows: (seg, rr), input time tl0 + rr
+            if (vecL) {
+                for (int idx = tid; idx < TB * R * (BB / 4); idx += 256) {
+                    const int row = idx / (BB / 4), q = idx - row * (BB / 4);
+                    const int seg = row / R, rr = row - seg * R;
+                    const int b = bb0 + seg, t = tl0 + rr, c = b0 + 4 * q;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (b < nb && t >= 0 && t < p.Tl && c < p.Bc)
+                        v = *reinterpret_cast<const float4*>(Lp + ((long)b * p.Tl + t) * p.Bc + c);
+                    *reinterpret_cast<float4*>(Ls + row * BB + 4 * q) = v;
+                }
+            } else {
+                for (int idx = tid; idx < TB * R * BB; idx += 256) {
+                    const int row = idx / BB, cl = idx - row * BB;
+                    const int seg = row / R, rr = row - seg * R;
+                    const int b = bb0 + seg, t = tl0 + rr, c = b0 + cl;
+                    float v = 0.f;
+                    if (b < nb && t >= 0 && t < p.Tl && c < p.Bc) v = Lp[((long)b * p.Tl + t) * p.Bc + c];
+                    Ls[row * BB + cl] = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int r2 = 0; r2 < RT / 2; ++r2) {
+                const int r = 2 * r2 + h;
+                const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+                const float av = Ss[r * BA + wa * 32 + (lane & 31)];
+                const float* lrow = Ls + (seg * R + tl * S) * BB + wb * 32 + (lane & 31);
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lrow[k * BB], acc[k], 0, 0, 0);
+            }
+        }
+    }
+    float* out = p.part + (long)split * p.slab;
+    const int b = b0 + wb * 32 + (lane & 31);
+    if (b < p.Bc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int a = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (a >= p.A) continue;
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[((long)a * p.Bc + b) * K + k] = acc[k][r];
+        }
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nsplit) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long)z * n + i];
+    out[i] = s;
+}
+
+struct Plan {
+    int tt_log2, TB, n_ttiles, nbg0, nbg1, nsplit, bps;
+};
+
+Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
+    Plan pl;
+    int lg = mg_ilog2_ceil(Ts);
+    if (lg > 5) lg = 5;
+    pl.tt_log2 = lg;
+    pl.TB = RT >> lg;
+    pl.n_ttiles = (int)mg_cdiv(Ts, 1 << lg);
+    pl.nbg0 = (int)mg_cdiv(nb0, pl.TB);
+    pl.nbg1 = nb1 > 0 ? (int)mg_cdiv(nb1, pl.TB) : 0;
+    const int ngroups = pl.nbg0 + pl.nbg1;
+    const long tiles = mg_cdiv(A, BA) * mg_cdiv(Bc, BB);
+    // aim for ~512 workgroups, at least 2 r-chunks per split, at most 64 slabs
+    long want = mg_cdiv(512, tiles);
+    long max_by_work = ((long)ngroups * pl.n_ttiles) / 2;
+    if (max_by_work < 1) max_by_work = 1;
+    if (want > max_by_work) want = max_by_work;
+    if (want > ngroups) want = ngroups;
+    if (want > 64) want = 64;
+    if (want < 1) want = 1;
+    pl.bps = (int)mg_cdiv(ngroups, want);
+    pl.nsplit = (int)mg_cdiv(ngroups, pl.bps);
+    return pl;
+}
+
+}  // namespace
+
+extern "C" size_t mg_wgrad_workspace_bytes(int A, int Bc, int K, int nb_total, int Ts) {
+    // upper bound over any (nb0, nb1) split of nb_total: nsplit <= min(64, #batch groups)
+    int lg = mg_ilog2_ceil(Ts);
+    if (lg > 5) lg = 5;
+    const int TB = RT >> lg;
+    long ns = mg_cdiv(nb_total, TB) + 1;
+    if (ns > 64) ns = 64;
+    return (size_t)ns * (size_t)A * (size_t)Bc * (size_t)K * sizeof(float);
+}
+
+extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* s1, const float* l1, int nb1,
+                        float* out, int Ts, int Tl, int A, int Bc, int K, int stride, void* work,
+                        size_t work_bytes, mg_stream_t stream) {
+    MG_CHECK_ARG(s0 && l0 && out && nb0 > 0, "mg_wgrad: null/empty segment 0");
+    MG_CHECK_ARG(nb1 == 0 || (s1 && l1), "mg_wgrad: null segment 1");
+    MG_CHECK_ARG(Ts > 0 && Tl > 0 && A > 0 && Bc > 0, "mg_wgrad: bad shape");
+    MG_CHECK_ARG(K == 1 || K == 3 || K == 5, "mg_wgrad: K=%d unsupported", K);
+    MG_CHECK_ARG(stride == 1 || stride == 2, "mg_wgrad: stride=%d unsupported", stride);
+    const Plan pl = make_plan(A, Bc, K, nb0, nb1, Ts);
+    const long slab = (long)A * Bc * K;
+    if (!work || work_bytes < (size_t)pl.nsplit * slab * sizeof(float)) {
+        mg_set_error("mg_wgrad: workspace too small (%zu < %zu)", work_bytes, (size_t)pl.nsplit * slab * sizeof(float));
+        return MG_EWORK;
+    }
+    WgradP p{};
+    p.s[0] = s0; p.l[0] = l0; p.nb[0] = nb0;
+    p.s[1] = s1; p.l[1] = l1; p.nb[1] = nb1;
+    p.part = (float*)work;
+    p.Ts = Ts; p.Tl = Tl; p.A = A; p.Bc = Bc;
+    p.tt_log2 = pl.tt_log2; p.n_ttiles = pl.n_ttiles;
+    p.bps = pl.bps; p.n_bgroups = pl.nbg0 + pl.nbg1; p.nbg0 = pl.nbg0;
+    p.slab = slab;
+    const int TT = 1 << pl.tt_log2;
+    const int R = (TT - 1) * stride + K;
+    const size_t lds = ((size_t)RT * BA + (size_t)pl.TB * R * BB) * sizeof(float);
+    dim3 grid((unsigned)mg_cdiv(A, BA), (unsigned)mg_cdiv(Bc, BB), (unsigned)pl.nsplit);
+    hipStream_t st = (hipStream_t)stream;
+#define MG_WG(S_, K_) hipLaunchKernelGGL((wgrad_kernel<S_, K_>), grid, dim3(256), lds, st, p)
+    if (stride == 1) {
+        if (K == 1) MG_WG(1, 1); else if (K == 3) MG_WG(1, 3); else MG_WG(1, 5);
+    } else {
+        if (K == 5) MG_WG(2, 5);
+        else { mg_set_error("mg_wgrad: stride 2 needs K=5"); return MG_EUNSUP; }
+    }
+#undef MG_WG
+    MG_CHECK_LAUNCH("wgrad_kernel");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(slab, 256)), dim3(256), 0, st,
+                       (const float*)work, out, slab, pl.nsplit);
+    MG_CHECK_LAUNCH("reduce_slabs_kernel");
+    return MG_OK;
+}

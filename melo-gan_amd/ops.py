@@ -1,0 +1,583 @@
+"""Thin, shape-checked Python wrappers over the C-ABI of libmelogan_hip.so.
+
+Every function takes fp32 CUDA (HIP) tensors, validates the shapes the kernel and its grid
+assume ON THE HOST (a wrong shape must never reach the GPU), and enqueues on PyTorch's
+current stream.  Activations are channels-last (B, T, C); weights keep the reference's
+state_dict layouts.  Nothing here falls back to PyTorch math.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_TANH, Epilogue  # noqa: F401
+
+Tensor = torch.Tensor
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t: Tensor, name: str, shape=None, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA/HIP tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def epilogue(out_shape, N, bias=None, scale=None, shift=None, zout=None, act=ACT_NONE, gref=None,
+             gact=ACT_NONE, emul=None, gscale=None, accumulate=False) -> Epilogue:
+    for nm, v in (("bias", bias), ("scale", scale), ("shift", shift), ("gscale", gscale)):
+        if v is not None:
+            _chk(v, nm, (N,))
+    for nm, v in (("zout", zout), ("gref", gref), ("emul", emul)):
+        if v is not None:
+            _chk(v, nm)
+            if v.numel() != _numel(out_shape):
+                raise ValueError(f"{nm}: numel {v.numel()} != output numel {_numel(out_shape)}")
+    if (scale is None) != (shift is None):
+        raise ValueError("scale and shift come in pairs")
+    return Epilogue(_p(bias), _p(scale), _p(shift), _p(zout), act, _p(gref), gact, _p(emul), _p(gscale),
+                    1 if accumulate else 0)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+# ---------------------------------------------------------------------------------------
+# window GEMMs
+# ---------------------------------------------------------------------------------------
+def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_sn: int, w_sc: int,
+                flip: bool = False, y_rows: Optional[int] = None, **epi) -> Tensor:
+    """Generic gather window-GEMM (see mg_conv1d_gather).  x: (B, Tin, Cin); y: (B, Ty, N) with
+    Ty >= Tout (rows beyond Tout are left untouched -- the generator's zero-pad branch)."""
+    _chk(x, "x")
+    _chk(w, "w")
+    _chk(y, "y")
+    if x.dim() != 3 or y.dim() != 3:
+        raise ValueError("x and y must be (B, T, C)")
+    B, Tin, Cin = x.shape
+    pad = (K - 1) // 2
+    Tout = (Tin + 2 * pad - K) // stride + 1
+    if y.shape[0] != B or y.shape[2] != N or y.shape[1] < Tout:
+        raise ValueError(f"y: expected (B={B}, >={Tout}, {N}), got {tuple(y.shape)}")
+    need = (N - 1) * w_sn + (Cin - 1) * w_sc + K
+    if w.numel() < need:
+        raise ValueError(f"w: numel {w.numel()} < {need} implied by strides")
+    e = epilogue((B, Tout, N), N, **epi)
+    if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
+        raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
+    rc = L.load().mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
+                                   Tin * Cin, y.shape[1] * N, C.byref(e), _stream())
+    L.check(rc, "mg_conv1d_gather")
+    return y
+
+
+def conv_scatter2(x: Tensor, w: Tensor, y: Tensor, N: int, w_sn: int, w_sc: int, odd: bool = False, **epi) -> Tensor:
+    """Stride-2 K=5 transposed window-GEMM (see mg_conv1d_scatter2).  x: (B, Tin, Cin); y: (B, Ty>=Tout, N),
+    Tout = 2*Tin, or 2*Tin-1 with odd=True (dgrad of a stride-2 conv over an odd-length input)."""
+    _chk(x, "x")
+    _chk(w, "w")
+    _chk(y, "y")
+    B, Tin, Cin = x.shape
+    Tout = 2 * Tin - (1 if odd else 0)
+    if y.dim() != 3 or y.shape[0] != B or y.shape[2] != N or y.shape[1] < Tout:
+        raise ValueError(f"y: expected (B={B}, >={Tout}, {N}), got {tuple(y.shape)}")
+    need = (N - 1) * w_sn + (Cin - 1) * w_sc + 5
+    if w.numel() < need:
+        raise ValueError(f"w: numel {w.numel()} < {need} implied by strides")
+    e = epilogue((B, Tout, N), N, **epi)
+    if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
+        raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
+    rc = L.load().mg_conv1d_scatter2(_p(x), _p(w), _p(y), B, Tin, Cin, N, Tout, w_sn, w_sc, Tin * Cin, y.shape[1] * N,
+                                     C.byref(e), _stream())
+    L.check(rc, "mg_conv1d_scatter2")
+    return y
+
+
+def conv1d_fwd(x, w, y, stride, **epi):
+    """nn.Conv1d(Cin, Cout, K, stride, padding=K//2) forward; w: (Cout, Cin, K)."""
+    Cout, Cin, K = w.shape
+    if x.shape[2] != Cin:
+        raise ValueError("conv1d_fwd: channel mismatch")
+    return conv_gather(x, w, y, Cout, K, stride, Cin * K, K, **epi)
+
+
+def conv1d_dgrad(dy, w, dx, stride, **epi):
+    """Data gradient of nn.Conv1d; w: (Cout, Cin, K); dy: (B, Tout, Cout) -> dx: (B, Tin, Cin)."""
+    Cout, Cin, K = w.shape
+    if dy.shape[2] != Cout:
+        raise ValueError("conv1d_dgrad: channel mismatch")
+    if stride == 1:
+        return conv_gather(dy, w, dx, Cin, K, 1, K, Cin * K, flip=True, **epi)
+    if K != 5:
+        raise ValueError("stride-2 dgrad needs K=5")
+    odd = dx.shape[1] == 2 * dy.shape[1] - 1
+    return conv_scatter2(dy, w, dx, Cin, K, Cin * K, odd=odd, **epi)
+
+
+def convT1d_fwd(x, w, y, **epi):
+    """nn.ConvTranspose1d(Cin, Cout, 5, stride=2, padding=2, output_padding=1) forward; w: (Cin, Cout, 5)."""
+    Cin, Cout, K = w.shape
+    if x.shape[2] != Cin or K != 5:
+        raise ValueError("convT1d_fwd: shape mismatch")
+    return conv_scatter2(x, w, y, Cout, K, Cout * K, **epi)
+
+
+def convT1d_dgrad(dy, w, dx, **epi):
+    """Data gradient of the stride-2 ConvTranspose1d: dx[u,ci] = sum dy[2u+k-2,co] w[ci,co,k]."""
+    Cin, Cout, K = w.shape
+    if dy.shape[2] != Cout:
+        raise ValueError("convT1d_dgrad: channel mismatch")
+    return conv_gather(dy, w, dx, Cin, K, 2, Cout * K, K, **epi)
+
+
+def linear_fwd(x, w, y, **epi):
+    """nn.Linear forward; x: (B, in), w: (out, in), y: (B, out)."""
+    out_f, in_f = w.shape
+    B = x.shape[0]
+    if x.shape[1] != in_f or tuple(y.shape) != (B, out_f):
+        raise ValueError(f"linear_fwd: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)}")
+    conv_gather(x.view(B, 1, in_f), w, y.view(B, 1, out_f), out_f, 1, 1, in_f, 1, **epi)
+    return y
+
+
+def linear_dgrad(dy, w, dx, **epi):
+    """dx = dy @ w; dy: (B, out), w: (out, in), dx: (B, in)."""
+    out_f, in_f = w.shape
+    B = dy.shape[0]
+    if dy.shape[1] != out_f or tuple(dx.shape) != (B, in_f):
+        raise ValueError("linear_dgrad: shape mismatch")
+    conv_gather(dy.view(B, 1, out_f), w, dx.view(B, 1, in_f), in_f, 1, 1, 1, in_f, **epi)
+    return dx
+
+
+# ---------------------------------------------------------------------------------------
+# weight gradients
+# ---------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "default") -> Tensor:
+    """Grow-only scratch buffer per (device, tag).  Allocation happens outside graph capture
+    because every engine warms up eagerly before capturing."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def wgrad(small: Tensor, large: Tensor, out: Tensor, K: int, stride: int,
+          small2: Optional[Tensor] = None, large2: Optional[Tensor] = None, work: Optional[Tensor] = None):
+    """out[a][b][k] = sum S[bt,u,a] * L[bt,u*stride+k-(K-1)/2,b] over one or two (S, L) segments."""
+    _chk(small, "small")
+    _chk(large, "large")
+    _chk(out, "out")
+    nb0, Ts, A = small.shape
+    if large.shape[0] != nb0:
+        raise ValueError("wgrad: batch mismatch")
+    Tl, Bc = large.shape[1], large.shape[2]
+    pad = (K - 1) // 2
+    if (Tl + 2 * pad - K) // stride + 1 != Ts and not (stride == 2 and Tl == 2 * Ts):
+        raise ValueError(f"wgrad: Ts={Ts} inconsistent with Tl={Tl}, K={K}, stride={stride}")
+    if out.numel() != A * Bc * K:
+        raise ValueError(f"wgrad: out numel {out.numel()} != {A * Bc * K}")
+    nb1 = 0
+    if small2 is not None:
+        _chk(small2, "small2")
+        _chk(large2, "large2")
+        nb1 = small2.shape[0]
+        if tuple(small2.shape[1:]) != (Ts, A) or tuple(large2.shape) != (nb1, Tl, Bc):
+            raise ValueError("wgrad: segment 1 shape mismatch")
+    lib = L.load()
+    need = lib.mg_wgrad_workspace_bytes(A, Bc, K, nb0 + nb1, Ts)
+    if work is None:
+        work = workspace(need, small.device, "wgrad")
+    if work.numel() * work.element_size() < need:
+        raise ValueError("wgrad: workspace too small")
+    rc = lib.mg_wgrad(_p(small), _p(large), nb0, _p(small2), _p(large2), nb1, _p(out), Ts, Tl, A, Bc, K, stride,
+                      _p(work), work.numel() * work.element_size(), _stream())
+    L.check(rc, "mg_wgrad")
+    return out
+
+
+def conv1d_wgrad(x, dy, dw, stride, x2=None, dy2=None):
+    """dw (Cout, Cin, K) for nn.Conv1d: S = dy, L = x."""
+    K = dw.shape[2]
+    return wgrad(dy, x, dw, K, stride, dy2, x2)
+
+
+def convT1d_wgrad(x, dy, dw):
+    """dw (Cin, Cout, 5) for the stride-2 ConvTranspose1d: S = x, L = dy."""
+    return wgrad(x, dy, dw, 5, 2)
+
+
+def linear_wgrad(x, dy, dw, x2=None, dy2=None):
+    """dw (out, in) = dy^T @ x (+ second segment)."""
+    B = x.shape[0]
+    s2 = l2 = None
+    if x2 is not None:
+        s2, l2 = dy2.view(dy2.shape[0], 1, -1), x2.view(x2.shape[0], 1, -1)
+    return wgrad(dy.view(B, 1, -1), x.view(B, 1, -1), dw, 1, 1, s2, l2)
+
+
+# ---------------------------------------------------------------------------------------
+# reductions / normalisation
+# ---------------------------------------------------------------------------------------
+def colsum(x: Tensor, out: Tensor, sumsq: Optional[Tensor] = None):
+    """out[c] = sum over all leading dims of x[..., c]."""
+    _chk(x, "x")
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    _chk(out, "out", (Cc,))
+    if sumsq is not None:
+        _chk(sumsq, "sumsq", (Cc,))
+    lib = L.load()
+    need = lib.mg_colsum_workspace_bytes(Cc)
+    work = workspace(need, x.device, "colsum")
+    L.check(lib.mg_colsum(_p(x), R, Cc, _p(out), _p(sumsq), _p(work), work.numel(), _stream()), "mg_colsum")
+    return out
+
+
+def bn_train_fwd(z, a, gamma, beta, running_mean, running_var, save_mean, save_invstd, act=ACT_RELU,
+                 momentum=0.1, eps=1e-5):
+    _chk(z, "z")
+    _chk(a, "a", z.shape)
+    Cc = z.shape[-1]
+    R = z.numel() // Cc
+    for nm, v in (("gamma", gamma), ("beta", beta), ("save_mean", save_mean), ("save_invstd", save_invstd)):
+        _chk(v, nm, (Cc,))
+    if running_mean is not None:
+        _chk(running_mean, "running_mean", (Cc,))
+        _chk(running_var, "running_var", (Cc,))
+    lib = L.load()
+    work = workspace(lib.mg_bn_workspace_bytes(Cc), z.device, "bn")
+    L.check(lib.mg_bn_train_fwd(_p(z), _p(a), R, Cc, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                momentum, eps, _p(save_mean), _p(save_invstd), act, _p(work), work.numel(),
+                                _stream()), "mg_bn_train_fwd")
+    return a
+
+
+def bn_train_bwd(da, a, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta, act=ACT_RELU):
+    _chk(da, "da", z.shape)
+    _chk(a, "a", z.shape)
+    _chk(z, "z")
+    _chk(dz, "dz", z.shape)
+    Cc = z.shape[-1]
+    R = z.numel() // Cc
+    for nm, v in (("gamma", gamma), ("save_mean", save_mean), ("save_invstd", save_invstd), ("dgamma", dgamma),
+                  ("dbeta", dbeta)):
+        _chk(v, nm, (Cc,))
+    lib = L.load()
+    work = workspace(lib.mg_bn_workspace_bytes(Cc), z.device, "bn")
+    L.check(lib.mg_bn_train_bwd(_p(da), _p(a), _p(z), _p(dz), R, Cc, _p(gamma), _p(save_mean), _p(save_invstd),
+                                _p(dgamma), _p(dbeta), act, _p(work), work.numel(), _stream()), "mg_bn_train_bwd")
+    return dz
+
+
+def bn_eval_fwd(z, a, gamma, beta, running_mean, running_var, act=ACT_RELU, eps=1e-5):
+    _chk(z, "z")
+    _chk(a, "a", z.shape)
+    Cc = z.shape[-1]
+    for nm, v in (("gamma", gamma), ("beta", beta), ("running_mean", running_mean), ("running_var", running_var)):
+        _chk(v, nm, (Cc,))
+    L.check(L.load().mg_bn_eval_fwd(_p(z), _p(a), z.numel() // Cc, Cc, _p(gamma), _p(beta), _p(running_mean),
+                                    _p(running_var), eps, act, _stream()), "mg_bn_eval_fwd")
+    return a
+
+
+def bn_fold(gamma, beta, running_mean, running_var, conv_bias, scale, shift, eps=1e-5):
+    Cc = gamma.numel()
+    for nm, v in (("gamma", gamma), ("beta", beta), ("running_mean", running_mean), ("running_var", running_var),
+                  ("scale", scale), ("shift", shift)):
+        _chk(v, nm, (Cc,))
+    if conv_bias is not None:
+        _chk(conv_bias, "conv_bias", (Cc,))
+    L.check(L.load().mg_bn_fold(_p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(conv_bias), eps,
+                                _p(scale), _p(shift), Cc, _stream()), "mg_bn_fold")
+
+
+def meanT_fwd(a, h):
+    _chk(a, "a")
+    B, T, Cc = a.shape
+    _chk(h, "h", (B, Cc))
+    L.check(L.load().mg_meanT_fwd(_p(a), _p(h), B, T, Cc, _stream()), "mg_meanT_fwd")
+    return h
+
+
+def meanT_bwd(dh, dz, gref=None, gact=ACT_NONE, gscale=None):
+    _chk(dz, "dz")
+    B, T, Cc = dz.shape
+    _chk(dh, "dh", (B, Cc))
+    if gref is not None:
+        _chk(gref, "gref", dz.shape)
+    if gscale is not None:
+        _chk(gscale, "gscale", (Cc,))
+    L.check(L.load().mg_meanT_bwd(_p(dh), _p(dz), B, T, Cc, _p(gref), gact, _p(gscale), _stream()), "mg_meanT_bwd")
+    return dz
+
+
+def layernorm_fwd(x, y, xhat, gamma, beta, eps=1e-5):
+    _chk(x, "x")
+    B, D = x.shape
+    _chk(y, "y", (B, D))
+    if xhat is not None:
+        _chk(xhat, "xhat", (B, D))
+    _chk(gamma, "gamma", (D,))
+    _chk(beta, "beta", (D,))
+    L.check(L.load().mg_layernorm_fwd(_p(x), _p(y), _p(xhat), B, D, _p(gamma), _p(beta), eps, _stream()),
+            "mg_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd_params(dy, xhat, dgamma, dbeta):
+    _chk(dy, "dy")
+    B, D = dy.shape
+    _chk(xhat, "xhat", (B, D))
+    _chk(dgamma, "dgamma", (D,))
+    _chk(dbeta, "dbeta", (D,))
+    L.check(L.load().mg_layernorm_bwd_params(_p(dy), _p(xhat), _p(dgamma), _p(dbeta), B, D, _stream()),
+            "mg_layernorm_bwd_params")
+
+
+# ---------------------------------------------------------------------------------------
+# critic head, GP, losses
+# ---------------------------------------------------------------------------------------
+def dhead_fwd(f, emb, w, bias, s):
+    _chk(f, "f")
+    B, F = f.shape
+    Be, E = (emb.shape if emb is not None else (0, 0))
+    if emb is not None:
+        _chk(emb, "emb")
+        if B % Be:
+            raise ValueError("dhead_fwd: B must be a multiple of emb rows")
+    if w.numel() != F + E:
+        raise ValueError("dhead_fwd: weight size mismatch")
+    _chk(w, "w")
+    _chk(bias, "bias")
+    _chk(s, "s", (B,))
+    L.check(L.load().mg_dhead_fwd(_p(f), _p(emb), _p(w), _p(bias), _p(s), B, Be, F, E, _stream()), "mg_dhead_fwd")
+    return s
+
+
+def dhead_bwd(ds, f, w, dU, demb=None, nb_emb=0):
+    _chk(f, "f")
+    B, F = f.shape
+    _chk(ds, "ds", (B,))
+    _chk(dU, "dU", (B, F))
+    _chk(w, "w")
+    Be = E = 0
+    if demb is not None:
+        _chk(demb, "demb")
+        Be, E = demb.shape
+        if w.numel() != F + E or nb_emb > B or nb_emb % Be:
+            raise ValueError("dhead_bwd: emb shape mismatch")
+    L.check(L.load().mg_dhead_bwd(_p(ds), _p(f), _p(w), _p(dU), _p(demb), B, Be, F, E, nb_emb, _stream()),
+            "mg_dhead_bwd")
+
+
+def dhead_wgrad(ds, f, emb, gf, dw, dbias, nb, ng):
+    _chk(f, "f")
+    F = f.shape[1]
+    Be, E = (emb.shape if emb is not None else (0, 0))
+    if nb > f.shape[0] or nb > ds.numel() or (gf is not None and (ng > gf.shape[0] or gf.shape[1] != F)):
+        raise ValueError("dhead_wgrad: row counts exceed tensors")
+    _chk(dw, "dw")
+    if dw.numel() != F + E:
+        raise ValueError("dhead_wgrad: dw size mismatch")
+    _chk(dbias, "dbias")
+    L.check(L.load().mg_dhead_wgrad(_p(ds), _p(f), _p(emb), _p(gf), _p(dw), _p(dbias), nb, ng if gf is not None else 0,
+                                    Be, F, E, _stream()), "mg_dhead_wgrad")
+
+
+def gp_interp(real, fake, alpha, xhat):
+    _chk(real, "real")
+    _chk(fake, "fake", real.shape)
+    _chk(xhat, "xhat", real.shape)
+    B = real.shape[0]
+    _chk(alpha, "alpha")
+    if alpha.numel() != B:
+        raise ValueError("gp_interp: alpha must have B elements")
+    L.check(L.load().mg_gp_interp(_p(real), _p(fake), _p(alpha), _p(xhat), B, real.numel() // B, _stream()),
+            "mg_gp_interp")
+    return xhat
+
+
+def gp_penalty(g, gbar, norms, gp, coef):
+    _chk(g, "g")
+    B = g.shape[0]
+    if gbar is not None:
+        _chk(gbar, "gbar", g.shape)
+    _chk(norms, "norms", (B,))
+    _chk(gp, "gp")
+    L.check(L.load().mg_gp_penalty(_p(g), _p(gbar), _p(norms), _p(gp), coef, B, g.numel() // B, _stream()),
+            "mg_gp_penalty")
+
+
+def wgan_d_loss(s, gp, lambda_gp, out, nb):
+    _chk(s, "s")
+    if s.numel() < 2 * nb or out.numel() < 3:
+        raise ValueError("wgan_d_loss: sizes")
+    L.check(L.load().mg_wgan_d_loss(_p(s), _p(gp), lambda_gp, _p(out), nb, _stream()), "mg_wgan_d_loss")
+
+
+def softmax_ce(logits, target, loss, dlogits, coef=1.0):
+    _chk(logits, "logits")
+    B, Cc = logits.shape
+    _chk(target, "target", (B,), torch.int64)
+    if dlogits is not None:
+        _chk(dlogits, "dlogits", (B, Cc))
+    L.check(L.load().mg_softmax_ce(_p(logits), _p(target), _p(loss), _p(dlogits), coef, B, Cc, _stream()),
+            "mg_softmax_ce")
+
+
+def neg_mean(s, out):
+    _chk(s, "s")
+    L.check(L.load().mg_neg_mean(_p(s), _p(out), s.numel(), _stream()), "mg_neg_mean")
+
+
+# ---------------------------------------------------------------------------------------
+# elementwise / optimiser
+# ---------------------------------------------------------------------------------------
+def fill(x, v):
+    _chk(x, "x")
+    L.check(L.load().mg_fill(_p(x), v, x.numel(), _stream()), "mg_fill")
+
+
+def axpby(x, y, a=1.0, b=0.0):
+    _chk(x, "x")
+    _chk(y, "y")
+    if x.numel() != y.numel():
+        raise ValueError("axpby: size mismatch")
+    L.check(L.load().mg_axpby(_p(x), _p(y), a, b, x.numel(), _stream()), "mg_axpby")
+
+
+def copy_cols(src, soff, dst, doff, ncols, accumulate=False):
+    _chk(src, "src")
+    _chk(dst, "dst")
+    if src.dim() != 2 or dst.dim() != 2 or src.shape[0] != dst.shape[0]:
+        raise ValueError("copy_cols: need 2-D tensors with equal rows")
+    if soff + ncols > src.shape[1] or doff + ncols > dst.shape[1]:
+        raise ValueError("copy_cols: column range out of bounds")
+    L.check(L.load().mg_copy_cols(_p(src), src.shape[1], soff, _p(dst), dst.shape[1], doff, src.shape[0], ncols,
+                                  1 if accumulate else 0, _stream()), "mg_copy_cols")
+
+
+def transpose_bcl_blc(x, y):
+    """y[b, l, c] = x[b, c, l]."""
+    _chk(x, "x")
+    B, Cc, Ln = x.shape
+    _chk(y, "y", (B, Ln, Cc))
+    L.check(L.load().mg_transpose_bcl_blc(_p(x), _p(y), B, Cc, Ln, _stream()), "mg_transpose_bcl_blc")
+    return y
+
+
+def act_bwd(dy, dx, gref=None, gact=ACT_NONE, emul=None):
+    _chk(dy, "dy")
+    _chk(dx, "dx")
+    n = dy.numel()
+    for v in (dx, gref, emul):
+        if v is not None and v.numel() != n:
+            raise ValueError("act_bwd: size mismatch")
+    L.check(L.load().mg_act_bwd(_p(dy), _p(gref), gact, _p(emul), _p(dx), n, _stream()), "mg_act_bwd")
+
+
+def adam_flat(p, g, m, v, state, lr, beta1, beta2, eps=1e-8, weight_decay=0.0, grad_scale=1.0, gs_dev=None):
+    n = p.numel()
+    for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, nm)
+        if t.numel() != n:
+            raise ValueError("adam_flat: size mismatch")
+    _chk(state, "state", (4,), torch.float64)
+    L.check(L.load().mg_adam_flat(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, _p(state),
+                                  grad_scale, _p(gs_dev), _stream()), "mg_adam_flat")
+
+
+def grad_norm_clip(g, max_norm, out):
+    _chk(g, "g")
+    _chk(out, "out")
+    lib = L.load()
+    work = workspace(lib.mg_grad_norm_workspace_bytes(g.numel()), g.device, "gnorm")
+    L.check(lib.mg_grad_norm_clip(_p(g), g.numel(), max_norm, _p(out), _p(work), work.numel(), _stream()),
+            "mg_grad_norm_clip")
+
+
+def reparam_fwd(mu, logvar, eps, z):
+    for t in (mu, logvar, eps, z):
+        _chk(t, "t", mu.shape)
+    L.check(L.load().mg_reparam_fwd(_p(mu), _p(logvar), _p(eps), _p(z), mu.numel(), _stream()), "mg_reparam_fwd")
+
+
+def vae_loss(recon, x, mu, logvar, beta, out, drecon=None, dmu=None, dlv=None):
+    _chk(recon, "recon")
+    _chk(x, "x", recon.shape)
+    _chk(mu, "mu")
+    _chk(logvar, "logvar", mu.shape)
+    L.check(L.load().mg_vae_loss(_p(recon), _p(x), x.numel(), _p(mu), _p(logvar), mu.numel(), beta, _p(out),
+                                 _p(drecon), _p(dmu), _p(dlv), _stream()), "mg_vae_loss")
+
+
+# ---------------------------------------------------------------------------------------
+# hipGraph capture + events
+# ---------------------------------------------------------------------------------------
+class Graph:
+    """hipGraph captured from whatever is enqueued on PyTorch's current stream between
+    begin() and end()."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+
+    def begin(self):
+        L.check(L.load().mg_graph_begin(_stream()), "mg_graph_begin")
+
+    def end(self):
+        L.check(L.load().mg_graph_end(_stream(), C.byref(self.handle)), "mg_graph_end")
+
+    def launch(self):
+        L.check(L.load().mg_graph_launch(self.handle, _stream()), "mg_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L.load().mg_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        L.check(L.load().mg_event_create(C.byref(self.h)), "mg_event_create")
+
+    def record(self):
+        L.check(L.load().mg_event_record(self.h, _stream()), "mg_event_record")
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float()
+        L.check(L.load().mg_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "mg_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            L.load().mg_event_destroy(self.h)
+        except Exception:
+            pass
