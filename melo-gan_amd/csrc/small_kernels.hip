@@ -33,28 +33,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                              const float* __restrict__ z,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int act, long R,
-                                                             int C, long rows_per, float* __restrict__ part,
+                                                             int C, long rows_per, double* __restrict__ part,
                                                              int want_sq) {
-    __shared__ float sh[2][4][64];
+    __shared__ double sh[2][4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const long r0 = (long)blockIdx.y * rows_per;
     long r1 = r0 + rows_per;
     if (r1 > R) r1 = R;
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;     // fp64 accumulation is free here: the kernel is HBM-bound
     if (c < C) {
         float mu = 0.f, is = 0.f;
         if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
         for (long r = r0 + ry; r < r1; r += 4) {
             const long i = r * C + c;
             if (MODE == 0) {
-                const float v = x[i];
+                const double v = (double)x[i];
                 s1 += v;
                 s2 += v * v;
             } else {
-                const float dy = x[i] * mg_act_grad(act, a[i]);
+                const double dy = (double)(x[i] * mg_act_grad(act, a[i]));
                 s1 += dy;
-                s2 += dy * (z[i] - mu) * is;
+                s2 += dy * (((double)z[i] - (double)mu) * (double)is);
             }
         }
     }
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     sh[1][ry][cx] = s2;
     __syncthreads();
     if (ry == 0 && c < C) {
-        const float t1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
-        const float t2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+        const double t1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+        const double t2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
         part[((long)blockIdx.y * 2 + 0) * C + c] = t1;
         if (want_sq) part[((long)blockIdx.y * 2 + 1) * C + c] = t2;
     }
@@ -80,7 +80,7 @@ RedPlan red_plan(long R) {
     return p;
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nsplit, int C, float* sum, float* sumsq) {
+__global__ void colsum_final_kernel(const double* __restrict__ part, int nsplit, int C, float* sum, float* sumsq) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
@@ -92,7 +92,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nsplit, 
     if (sumsq) sumsq[c] = (float)s2;
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nsplit, int C, long R, float momentum,
+__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nsplit, int C, long R, float momentum,
                                       float eps, float* running_mean, float* running_var, float* save_mean,
                                       float* save_invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,8 +120,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ z, float* __restrict__
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
-    const float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-    a[i] = mg_act(act, v);
+    // fp64 per-element math (free at HBM-bound rates; matches ATen's CPU accumulate type)
+    const double v = ((double)z[i] - (double)mean[c]) * (double)invstd[c] * (double)gamma[c] + (double)beta[c];
+    a[i] = mg_act(act, (float)v);
 }
 
 __global__ void bn_eval_kernel(const float* __restrict__ z, float* __restrict__ a, long n, int C,
@@ -143,8 +144,8 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] + ((cb ? cb[c] : 0.f) - rm[c]) * s;
 }
 
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nsplit, int C, float* dgamma, float* dbeta,
-                                    float* sums /* [2][C] */) {
+__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nsplit, int C, float* dgamma, float* dbeta,
+                                    double* sums /* [2][C] */) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
@@ -154,21 +155,22 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nsplit, 
     }
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
-    sums[c] = (float)s1;
-    sums[C + c] = (float)s2;
+    sums[c] = s1;
+    sums[C + c] = s2;
 }
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ a,
                                     const float* __restrict__ z, float* __restrict__ dz, long n, int C, long R,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ sums, int act) {
+                                    const float* __restrict__ invstd, const double* __restrict__ sums, int act) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
-    const float dy = da[i] * mg_act_grad(act, a[i]);
-    const float xh = (z[i] - mean[c]) * invstd[c];
-    const float invR = 1.f / (float)R;
-    dz[i] = gamma[c] * invstd[c] * (dy - sums[c] * invR - xh * sums[C + c] * invR);
+    const double dy = (double)(da[i] * mg_act_grad(act, a[i]));
+    const double is = (double)invstd[c];
+    const double xh = ((double)z[i] - (double)mean[c]) * is;
+    const double invR = 1.0 / (double)R;
+    dz[i] = (float)((double)gamma[c] * is * (dy - sums[c] * invR - xh * sums[C + c] * invR));
 }
 
 // ---------------- mean over time ----------------
@@ -508,7 +510,7 @@ inline unsigned nblk(long n, int bs = 256) { return (unsigned)mg_cdiv(n, bs); }
 
 extern "C" {
 
-size_t mg_colsum_workspace_bytes(int C) { return (size_t)RED_SPLITS * 2 * (size_t)C * sizeof(float) + 2 * (size_t)C * sizeof(float); }
+size_t mg_colsum_workspace_bytes(int C) { return ((size_t)RED_SPLITS + 1) * 2 * (size_t)C * sizeof(double); }
 size_t mg_bn_workspace_bytes(int C) { return mg_colsum_workspace_bytes(C); }
 
 int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq, void* work, size_t work_bytes,
@@ -518,8 +520,8 @@ int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq, void* wor
     const RedPlan pl = red_plan(R);
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, x, nullptr, nullptr, nullptr, nullptr, 0, R, C,
-                       pl.rows_per, (float*)work, sumsq ? 1 : 0);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const float*)work, pl.nsplit, C, sum, sumsq);
+                       pl.rows_per, (double*)work, sumsq ? 1 : 0);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, sum, sumsq);
     MG_CHECK_LAUNCH("colsum");
     return MG_OK;
 }
@@ -533,8 +535,8 @@ int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma,
     const RedPlan pl = red_plan(R);
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, z, nullptr, nullptr, nullptr, nullptr, 0, R, C,
-                       pl.rows_per, (float*)work, 1);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const float*)work, pl.nsplit, C, R,
+                       pl.rows_per, (double*)work, 1);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, R,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, z, a, R * C, C, gamma, beta, save_mean,
                        save_invstd, act);
@@ -548,15 +550,15 @@ int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, 
     MG_CHECK_ARG(da && a && z && dz && gamma && save_mean && save_invstd && dgamma && dbeta, "mg_bn_train_bwd: bad args");
     if (!work || work_bytes < mg_bn_workspace_bytes(C)) { mg_set_error("mg_bn_train_bwd: workspace too small"); return MG_EWORK; }
     const RedPlan pl = red_plan(R);
-    float* part = (float*)work;
-    float* sums = part + (size_t)RED_SPLITS * 2 * C;
+    double* part = (double*)work;
+    double* sums = part + (size_t)RED_SPLITS * 2 * C;
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), 0, ST, da, a, z, save_mean, save_invstd, act, R, C,
                        pl.rows_per, part, 1);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const float*)part, pl.nsplit, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const double*)part, pl.nsplit, C, dgamma,
                        dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, da, a, z, dz, R * C, C, R, gamma,
-                       save_mean, save_invstd, (const float*)sums, act);
+                       save_mean, save_invstd, (const double*)sums, act);
     MG_CHECK_LAUNCH("bn_train_bwd");
     return MG_OK;
 }

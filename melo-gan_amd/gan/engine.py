@@ -1,0 +1,651 @@
+"""GanEngine -- the WGAN-GP critic step and the generator step of Melo-GAN as explicit launch
+sequences over libmelogan_hip (no autograd tape).
+
+Restates /root/reference/src/gan/train_gan.py:183-205 (D-step) and :211-251 (G-step) with
+hand-derived backward passes:
+
+  * activations are channels-last (B, T, C) end to end -- the reference's permutes
+    (src/gan/models.py:73,159; ed_model.py:65) disappear;
+  * the three critic evaluations of the D-step (real, fake, x_hat) run as ONE batch of 3B, and
+    so does their backward: the Wasserstein terms back-propagate ds = -1/B, +1/B and the
+    gradient-penalty's autograd.grad(grad_outputs=ones) (src/gan/utils.py:80-87) back-propagates
+    ds = 1 -- the same network, three upstream coefficients;
+  * the penalty's second-order term is a hand-derived "tangent" forward pass through the critic
+    with the LeakyReLU masks of the x_hat pass (D is piecewise linear: no BatchNorm,
+    src/gan/models.py:144-146), after which every weight gradient is one two-segment wgrad:
+    [real,fake | tangent] activations against [Wasserstein | penalty] output gradients;
+  * parameters, gradients and Adam moments of each optimiser (D; G+E_num, as
+    train_gan.py:136-145) live in ONE flat fp32 buffer each -> one fused Adam launch and one
+    all-reduce bucket per step; state_dict tensors are views into it.
+
+Randomness (noise, alpha, dropout keep-masks) is an INPUT of every step, so parity runs inject
+the oracle's draws and production runs fill the same buffers from the device RNG.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU
+
+Tensor = torch.Tensor
+BN_EPS, BN_MOM, P_DROP = 1e-5, 0.1, 0.2
+
+
+# ------------------------------------------------------------------------------------------
+# parameter specs (reference state_dict names/shapes)
+# ------------------------------------------------------------------------------------------
+def feature_encoder_spec(in_dim=6, hidden_dims=(256, 128), out_dim=128):
+    """src/gan/feature_encoder.py:16-42."""
+    spec = OrderedDict([("net.0.weight", (in_dim,)), ("net.0.bias", (in_dim,))])
+    prev, idx = in_dim, 1
+    for h in hidden_dims:
+        spec[f"net.{idx}.weight"] = (h, prev)
+        spec[f"net.{idx}.bias"] = (h,)
+        prev, idx = h, idx + 3
+    spec[f"net.{idx}.weight"] = (out_dim, prev)
+    spec[f"net.{idx}.bias"] = (out_dim,)
+    return spec
+
+
+def generator_spec(noise_dim, latent_dim, mode, hidden, max_notes, note_dim, numeric_embed_dim):
+    """src/gan/models.py:86-106, :20-27, :33-64."""
+    in_dim = noise_dim + numeric_embed_dim + (latent_dim if mode == "conditioning" else 0)
+    red = max(1, max_notes // 8)
+    return OrderedDict([
+        ("noise_to_latent.net.0.weight", (hidden, in_dim)), ("noise_to_latent.net.0.bias", (hidden,)),
+        ("noise_to_latent.net.2.weight", (latent_dim, hidden)), ("noise_to_latent.net.2.bias", (latent_dim,)),
+        ("decoder.pre.0.weight", (512, latent_dim)), ("decoder.pre.0.bias", (512,)),
+        ("decoder.pre.2.weight", (256 * red, 512)), ("decoder.pre.2.bias", (256 * red,)),
+        ("decoder.deconv.0.weight", (256, 128, 5)), ("decoder.deconv.0.bias", (128,)),
+        ("decoder.deconv.1.weight", (128,)), ("decoder.deconv.1.bias", (128,)),
+        ("decoder.deconv.3.weight", (128, 64, 5)), ("decoder.deconv.3.bias", (64,)),
+        ("decoder.deconv.4.weight", (64,)), ("decoder.deconv.4.bias", (64,)),
+        ("decoder.deconv.6.weight", (64, note_dim, 5)), ("decoder.deconv.6.bias", (note_dim,)),
+    ])
+
+
+def discriminator_spec(note_dim, emb_dim=256, numeric_embed_dim=0):
+    """src/gan/models.py:137-157."""
+    return OrderedDict([
+        ("conv.0.weight", (64, note_dim, 5)), ("conv.0.bias", (64,)),
+        ("conv.2.weight", (128, 64, 5)), ("conv.2.bias", (128,)),
+        ("conv.4.weight", (256, 128, 5)), ("conv.4.bias", (256,)),
+        ("fc.1.weight", (emb_dim, 256)), ("fc.1.bias", (emb_dim,)),
+        ("real_fake.weight", (1, emb_dim + numeric_embed_dim)), ("real_fake.bias", (1,)),
+    ])
+
+
+def emotion_disc_spec(cfg: dict):
+    """src/emotion_discriminator/ed_model.py:52-58,115-145.  Returns (params, buffers, conv channel list)."""
+    spec, bufs, chans = OrderedDict(), OrderedDict(), []
+    prev = cfg.get("latent_dim", 128)
+    if cfg.get("input_mode", "latent") == "notes":
+        hid = cfg.get("notes_hidden", 256)
+        in_ch, ch = cfg.get("note_dim", 4), 64
+        for i in range(cfg.get("notes_blocks", 4)):
+            k = 5 if i == 0 else 3
+            chans.append((in_ch, ch, k))
+            spec[f"encoder.conv.{i}.net.0.weight"] = (ch, in_ch, k)
+            spec[f"encoder.conv.{i}.net.0.bias"] = (ch,)
+            spec[f"encoder.conv.{i}.net.1.weight"] = (ch,)
+            spec[f"encoder.conv.{i}.net.1.bias"] = (ch,)
+            bufs[f"encoder.conv.{i}.net.1.running_mean"] = (ch,)
+            bufs[f"encoder.conv.{i}.net.1.running_var"] = (ch,)
+            in_ch, ch = ch, min(ch * 2, hid)
+        spec["encoder.project.weight"] = (hid, in_ch)
+        spec["encoder.project.bias"] = (hid,)
+        prev = hid
+    idx = 0
+    for h in tuple(cfg.get("mlp_hidden", (256, 128))):
+        spec[f"classifier.net.{idx}.weight"] = (h, prev)
+        spec[f"classifier.net.{idx}.bias"] = (h,)
+        prev, idx = h, idx + 3
+    spec["classifier.head.weight"] = (cfg.get("n_classes", 4), prev)
+    spec["classifier.head.bias"] = (cfg.get("n_classes", 4),)
+    return spec, bufs, chans
+
+
+class FlatParams:
+    """All tensors of one optimiser in a single flat fp32 buffer (+ grads, Adam m/v, step state)."""
+
+    def __init__(self, spec: "OrderedDict[str, tuple]", device, with_opt: bool = True):
+        self.spec = spec
+        self.n = sum(math.prod(s) for s in spec.values())
+        pad = (-self.n) % 4
+        self.data = torch.zeros(self.n + pad, device=device)
+        self.p: Dict[str, Tensor] = OrderedDict()
+        off = 0
+        self.offsets = {}
+        for k, s in spec.items():
+            n = math.prod(s)
+            self.p[k] = self.data[off:off + n].view(s)
+            self.offsets[k] = (off, n)
+            off += n
+        self.g: Dict[str, Tensor] = OrderedDict()
+        if with_opt:
+            self.grad = torch.zeros_like(self.data)
+            self.m = torch.zeros_like(self.data)
+            self.v = torch.zeros_like(self.data)
+            self.state = torch.zeros(4, dtype=torch.float64, device=device)
+            for k, s in spec.items():
+                o, n = self.offsets[k]
+                self.g[k] = self.grad[o:o + n].view(s)
+
+    def load(self, params: Dict[str, Tensor], prefix: str = ""):
+        for k in self.spec:
+            src = params[prefix + k] if (prefix + k) in params else params[k]
+            if tuple(src.shape) != tuple(self.spec[k]):
+                raise ValueError(f"{k}: shape {tuple(src.shape)} != {self.spec[k]}")
+            self.p[k].copy_(src.to(torch.float32))
+
+    def state_dict(self) -> "OrderedDict[str, Tensor]":
+        return OrderedDict((k, v.detach().cpu().clone()) for k, v in self.p.items())
+
+
+class GanEngine:
+    """One replica of the GAN training state on one GPU."""
+
+    def __init__(self, cfg: dict, ed_cfg: dict, device="cuda", batch_size: Optional[int] = None):
+        self.cfg, self.ed_cfg = dict(cfg), dict(ed_cfg)
+        self.dev = torch.device(device)
+        B = self.B = int(batch_size or cfg.get("BATCH_SIZE", 32))
+        T = self.T = int(cfg["MAX_NOTES"])
+        C = self.C = int(cfg["NOTE_DIM"])
+        if T < 8:
+            raise ValueError("MAX_NOTES < 8 (the reference's trim branch) is not supported")
+        self.noise_dim, self.latent_dim = int(cfg["NOISE_DIM"]), int(cfg["LATENT_DIM"])
+        self.mode = cfg.get("INTEGRATION_MODE", "conditioning")
+        self.num_in = int(cfg.get("NUMERIC_INPUT_DIM", 6))
+        self.E = int(cfg.get("ENCODER_OUT_DIM", 128))
+        self.enc_hidden = tuple(cfg.get("ENCODER_HIDDEN", [256, 128]))
+        if len(self.enc_hidden) != 2:
+            raise ValueError("ENCODER_HIDDEN must have two entries (the reference default)")
+        self.lambda_gp = float(cfg.get("LAMBDA_GP", 10.0))
+        self.lambda_emo = float(cfg.get("LAMBDA_EMOTION", 1.0))
+        self.lr_g, self.lr_d = float(cfg["LR_G"]), float(cfg["LR_D"])
+        self.betas = (float(cfg.get("BETA1", 0.5)), float(cfg.get("BETA2", 0.9)))
+        self.ed_mode = ed_cfg.get("input_mode", "notes")
+        self.red = max(1, T // 8)
+        self.in_dim = self.noise_dim + self.E + (self.latent_dim if self.mode == "conditioning" else 0)
+        d = self.dev
+
+        # ---- parameters ----
+        gspec = generator_spec(self.noise_dim, self.latent_dim, self.mode, 512, T, C, self.E)
+        espec = feature_encoder_spec(self.num_in, self.enc_hidden, self.E)
+        ge = OrderedDict([("G." + k, s) for k, s in gspec.items()] + [("E." + k, s) for k, s in espec.items()])
+        self.GE = FlatParams(ge, d)
+        self.D = FlatParams(discriminator_spec(C, 256, self.E), d)
+        edspec, edbufs, self.ed_chans = emotion_disc_spec(self.ed_cfg)
+        self.ED = FlatParams(edspec, d, with_opt=False)
+        self.EDbuf = {k: (torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d))
+                      for k, s in edbufs.items()}
+        self.Gbuf = {"decoder.deconv.1.running_mean": torch.zeros(128, device=d),
+                     "decoder.deconv.1.running_var": torch.ones(128, device=d),
+                     "decoder.deconv.4.running_mean": torch.zeros(64, device=d),
+                     "decoder.deconv.4.running_var": torch.ones(64, device=d)}
+        self.num_batches_tracked = 0
+        self.ed_scale = [torch.empty(co, device=d) for (_, co, _) in self.ed_chans]
+        self.ed_shift = [torch.empty(co, device=d) for (_, co, _) in self.ed_chans]
+
+        # ---- static inputs ----
+        z = lambda *s: torch.zeros(*s, device=d)  # noqa: E731
+        self.numeric, self.latent = z(B, self.num_in), z(B, self.latent_dim)
+        self.emot_idx = torch.zeros(B, dtype=torch.int64, device=d)
+        self.noise, self.alpha = z(B, self.noise_dim), z(B)
+        self.dmask = [z(B, h) for h in self.enc_hidden]         # keep-mask * 1/(1-p)
+
+        # ---- E_num / G activations ----
+        h1, h2 = self.enc_hidden
+        self.e_x0, self.e_xhat = z(B, self.num_in), z(B, self.num_in)
+        self.e_z1, self.e_h1, self.e_z2, self.e_h2, self.emb = z(B, h1), z(B, h1), z(B, h2), z(B, h2), z(B, self.E)
+        self.gin, self.a_n0, self.lat = z(B, self.in_dim), z(B, 512), z(B, self.latent_dim)
+        self.a_p0, self.a_p2 = z(B, 512), z(B, 256 * self.red)
+        self.y0 = z(B, self.red, 256)
+        self.z_d0, self.a_d0 = z(B, 2 * self.red, 128), z(B, 2 * self.red, 128)
+        self.z_d3, self.a_d3 = z(B, 4 * self.red, 64), z(B, 4 * self.red, 64)
+        self.bn_mean = [z(128), z(64)]
+        self.bn_invstd = [z(128), z(64)]
+        self.L3 = 8 * self.red
+
+        # ---- critic activations for 3B rows: [real | fake | x_hat] ----
+        c1 = lambda t: (t - 1) // 2 + 1  # noqa: E731
+        self.T1, self.T2, self.T3 = c1(T), c1(c1(T)), c1(c1(c1(T)))
+        Bd = 3 * B
+        self.X0 = z(Bd, T, C)
+        self.A1, self.A2, self.A3 = z(Bd, self.T1, 64), z(Bd, self.T2, 128), z(Bd, self.T3, 256)
+        self.H, self.Fh, self.s = z(Bd, 256), z(Bd, 256), z(Bd)
+        self.dU, self.dH = z(Bd, 256), z(Bd, 256)
+        self.dZ3, self.dZ2, self.dZ1 = z(Bd, self.T3, 256), z(Bd, self.T2, 128), z(Bd, self.T1, 64)
+        self.gx = z(B, T, C)
+        self.TAN0, self.TAN1, self.TAN2 = z(B, T, C), z(B, self.T1, 64), z(B, self.T2, 128)
+        self.TZ3, self.ghb, self.gfb = z(B, self.T3, 256), z(B, 256), z(B, 256)
+        self.norms, self.gp = z(B), z(1)
+        self.ds_d = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B), torch.ones(B)]).to(d)
+        self.ds_g = torch.full((B,), -1.0 / B, device=d)
+        self.loss_d_out, self.adv, self.emo = z(3), z(1), z(1)
+
+        # ---- G-step extras ----
+        self.notes = z(B, T, C)                   # generator output (G-step)
+        self.dnotes = z(B, T, C)
+        self.dn_dense = z(B, self.L3, C) if self.L3 != T else None
+        self.demb = z(B, self.E)
+        self.d_ad3, self.d_zd3 = z(B, 4 * self.red, 64), z(B, 4 * self.red, 64)
+        self.d_ad0, self.d_zd0 = z(B, 2 * self.red, 128), z(B, 2 * self.red, 128)
+        self.d_y0, self.d_p2 = z(B, self.red, 256), z(B, 256 * self.red)
+        self.d_p0, self.d_lat, self.d_n0, self.d_gin = z(B, 512), z(B, self.latent_dim), z(B, 512), z(B, self.in_dim)
+        self.d_ez2, self.d_ez1, self.d_ex0 = z(B, h2), z(B, h1), z(B, self.num_in)
+        # emotion discriminator
+        self.ed_z = [z(B, T, co) for (_, co, _) in self.ed_chans]
+        self.ed_a = [z(B, T, co) for (_, co, _) in self.ed_chans]
+        self.ed_dz = [z(B, T, co) for (_, co, _) in self.ed_chans]
+        hid = self.ed_cfg.get("notes_hidden", 256)
+        mh = tuple(self.ed_cfg.get("mlp_hidden", (256, 128)))
+        self.ed_feat_dim = hid if self.ed_mode == "notes" else self.ed_cfg.get("latent_dim", 128)
+        if self.ed_mode != "notes" and self.ed_feat_dim != self.latent_dim:
+            raise ValueError("ED latent_dim must equal the generator LATENT_DIM in 'latent' mode")
+        self.ed_pool, self.ed_proj = z(B, self.ed_chans[-1][1] if self.ed_chans else 1), z(B, hid)
+        self.ed_cz = [z(B, h) for h in mh]
+        self.ed_ca = [z(B, h) for h in mh]
+        self.ed_dcz = [z(B, h) for h in mh]
+        self.n_classes = self.ed_cfg.get("n_classes", 4)
+        self.logits, self.dlogits = z(B, self.n_classes), z(B, self.n_classes)
+        self.ed_dproj, self.ed_dpool = z(B, hid), z(B, self.ed_pool.shape[1])
+        self.ed_dfeat = z(B, self.ed_feat_dim)
+        self._graphs = {}
+        # hipGraph capture is illegal on the null stream: every step runs on this side stream
+        self.stream = torch.cuda.Stream(device=d)
+        self.world_size = 1
+        self._ed_folded = False
+
+    # -------------------------------------------------------------------------------------
+    # state in / out
+    # -------------------------------------------------------------------------------------
+    def load_state(self, PE, PG, BG, PD, PED, BED):
+        """Load CPU dicts keyed like the reference's state_dicts."""
+        self.GE.load({**{"G." + k: v for k, v in PG.items()}, **{"E." + k: v for k, v in PE.items()}})
+        self.D.load(PD)
+        self.ED.load(PED)
+        for k in self.Gbuf:
+            self.Gbuf[k].copy_(BG[k])
+        for k in self.EDbuf:
+            self.EDbuf[k].copy_(BED[k])
+        self._ed_folded = False
+
+    def init_weights(self, seed: int = 42):
+        """weights_init (src/gan/utils.py:37-45): N(0, 0.02) on every Conv*/Linear* weight of E_num, G, D,
+        biases 0; BatchNorm/LayerNorm gamma=1, beta=0.  The frozen ED keeps a deterministic random fill
+        (the reference tolerates a missing checkpoint, train_gan.py:127-128)."""
+        g = torch.Generator().manual_seed(seed)
+        for fp in (self.GE, self.D):
+            for k, s in fp.spec.items():
+                if k.endswith("bias"):
+                    fp.p[k].zero_()
+                elif len(s) == 1:
+                    fp.p[k].fill_(1.0)
+                else:
+                    fp.p[k].copy_(torch.empty(s).normal_(0.0, 0.02, generator=g))
+        for k, s in self.ED.spec.items():
+            if k.endswith("bias"):
+                self.ED.p[k].zero_()
+            elif len(s) == 1:
+                self.ED.p[k].fill_(1.0)
+            else:
+                fan_in = math.prod(s[1:])
+                bound = 1.0 / math.sqrt(fan_in)
+                self.ED.p[k].copy_((torch.rand(s, generator=g) * 2 - 1) * bound)
+        self._ed_folded = False
+
+    def state_dicts(self):
+        """{'G','E_num','D','ED'} -> reference-format state_dicts (CPU)."""
+        G, E = OrderedDict(), OrderedDict()
+        for k, v in self.GE.p.items():
+            (G if k.startswith("G.") else E)[k[2:]] = v.detach().cpu().clone()
+        out_g = OrderedDict()
+        for k, v in G.items():
+            out_g[k] = v
+            if k in ("decoder.deconv.1.bias", "decoder.deconv.4.bias"):     # BN buffers follow weight/bias
+                base = k[:-len("bias")]
+                out_g[base + "running_mean"] = self.Gbuf[base + "running_mean"].cpu().clone()
+                out_g[base + "running_var"] = self.Gbuf[base + "running_var"].cpu().clone()
+                out_g[base + "num_batches_tracked"] = torch.tensor(self.num_batches_tracked, dtype=torch.int64)
+        ed = self.ED.state_dict()
+        for k, v in self.EDbuf.items():
+            ed[k] = v.cpu().clone()
+        return {"G": out_g, "E_num": E, "D": self.D.state_dict(), "ED": ed}
+
+    def set_batch(self, real: Tensor, numeric: Tensor, latent: Optional[Tensor], emot_idx: Tensor):
+        self.X0[:self.B].copy_(real, non_blocking=True)
+        self.numeric.copy_(numeric, non_blocking=True)
+        if latent is not None:
+            self.latent.copy_(latent, non_blocking=True)
+        self.emot_idx.copy_(emot_idx, non_blocking=True)
+
+    def set_randoms(self, noise: Tensor, drop_masks: Optional[Sequence[Tensor]], alpha: Optional[Tensor] = None):
+        """Injected randomness.  drop_masks are {0,1} keep-masks (None => eval mode, no dropout)."""
+        self.noise.copy_(noise, non_blocking=True)
+        if alpha is not None:
+            self.alpha.copy_(alpha.reshape(-1), non_blocking=True)
+        if drop_masks is not None:
+            for dst, m in zip(self.dmask, drop_masks):
+                dst.copy_(m.to(torch.float32) * (1.0 / (1.0 - P_DROP)), non_blocking=True)
+
+    def draw_randoms(self, with_alpha: bool):
+        """Production path: device RNG (torch's Philox generator) straight into the static buffers."""
+        self.noise.normal_()
+        if with_alpha:
+            self.alpha.uniform_()
+        for m in self.dmask:
+            m.uniform_()
+            m.copy_((m >= P_DROP).to(torch.float32) * (1.0 / (1.0 - P_DROP)))
+
+    # -------------------------------------------------------------------------------------
+    # forward pieces
+    # -------------------------------------------------------------------------------------
+    def _gp(self, k):
+        return self.GE.p["G." + k]
+
+    def _ep(self, k):
+        return self.GE.p["E." + k]
+
+    def _e_fwd(self, train: bool):
+        """FeatureEncoder.forward (src/gan/feature_encoder.py:43-45)."""
+        P = self._ep
+        ops.layernorm_fwd(self.numeric, self.e_x0, self.e_xhat, P("net.0.weight"), P("net.0.bias"))
+        m1, m2 = (self.dmask if train else (None, None))
+        ops.linear_fwd(self.e_x0, P("net.1.weight"), self.e_h1, bias=P("net.1.bias"), zout=self.e_z1, act=ACT_GELU, emul=m1)
+        ops.linear_fwd(self.e_h1, P("net.4.weight"), self.e_h2, bias=P("net.4.bias"), zout=self.e_z2, act=ACT_GELU, emul=m2)
+        ops.linear_fwd(self.e_h2, P("net.7.weight"), self.emb, bias=P("net.7.bias"))
+
+    def _g_fwd(self, out: Tensor, train: bool):
+        """Generator.forward (src/gan/models.py:108-130, :66-83) into `out` (B, T, C)."""
+        P = self._gp
+        ops.copy_cols(self.noise, 0, self.gin, 0, self.noise_dim)
+        ops.copy_cols(self.emb, 0, self.gin, self.noise_dim, self.E)
+        if self.mode == "conditioning":
+            ops.copy_cols(self.latent, 0, self.gin, self.noise_dim + self.E, self.latent_dim)
+        ops.linear_fwd(self.gin, P("noise_to_latent.net.0.weight"), self.a_n0, bias=P("noise_to_latent.net.0.bias"), act=ACT_RELU)
+        ops.linear_fwd(self.a_n0, P("noise_to_latent.net.2.weight"), self.lat, bias=P("noise_to_latent.net.2.bias"))
+        ops.linear_fwd(self.lat, P("decoder.pre.0.weight"), self.a_p0, bias=P("decoder.pre.0.bias"), act=ACT_RELU)
+        ops.linear_fwd(self.a_p0, P("decoder.pre.2.weight"), self.a_p2, bias=P("decoder.pre.2.bias"), act=ACT_RELU)
+        ops.transpose_bcl_blc(self.a_p2.view(self.B, 256, self.red), self.y0)
+        ops.convT1d_fwd(self.y0, P("decoder.deconv.0.weight"), self.z_d0, bias=P("decoder.deconv.0.bias"))
+        self._bn(self.z_d0, self.a_d0, "decoder.deconv.1", 0, train)
+        ops.convT1d_fwd(self.a_d0, P("decoder.deconv.3.weight"), self.z_d3, bias=P("decoder.deconv.3.bias"))
+        self._bn(self.z_d3, self.a_d3, "decoder.deconv.4", 1, train)
+        ops.convT1d_fwd(self.a_d3, P("decoder.deconv.6.weight"), out, bias=P("decoder.deconv.6.bias"))
+        if train:
+            self.num_batches_tracked += 1
+
+    def _bn(self, z, a, name, i, train):
+        P = self._gp
+        if train:
+            ops.bn_train_fwd(z, a, P(name + ".weight"), P(name + ".bias"), self.Gbuf[name + ".running_mean"],
+                             self.Gbuf[name + ".running_var"], self.bn_mean[i], self.bn_invstd[i], ACT_RELU, BN_MOM, BN_EPS)
+        else:
+            ops.bn_eval_fwd(z, a, P(name + ".weight"), P(name + ".bias"), self.Gbuf[name + ".running_mean"],
+                            self.Gbuf[name + ".running_var"], ACT_RELU, BN_EPS)
+
+    def _d_fwd(self, x: Tensor, nb: int):
+        """Discriminator.forward (src/gan/models.py:158-169) on the first nb rows of the critic buffers."""
+        P = self.D.p
+        ops.conv1d_fwd(x, P["conv.0.weight"], self.A1[:nb], 2, bias=P["conv.0.bias"], act=ACT_LRELU)
+        ops.conv1d_fwd(self.A1[:nb], P["conv.2.weight"], self.A2[:nb], 2, bias=P["conv.2.bias"], act=ACT_LRELU)
+        ops.conv1d_fwd(self.A2[:nb], P["conv.4.weight"], self.A3[:nb], 2, bias=P["conv.4.bias"], act=ACT_LRELU)
+        ops.meanT_fwd(self.A3[:nb], self.H[:nb])
+        ops.linear_fwd(self.H[:nb], P["fc.1.weight"], self.Fh[:nb], bias=P["fc.1.bias"], act=ACT_LRELU)
+        ops.dhead_fwd(self.Fh[:nb], self.emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb])
+
+    def _d_bwd_input(self, ds: Tensor, nb: int, demb: Optional[Tensor]):
+        """Back-propagate ds through the critic down to dZ1 (grad wrt conv.0's pre-activation)."""
+        P = self.D.p
+        ops.dhead_bwd(ds, self.Fh[:nb], P["real_fake.weight"].view(-1), self.dU[:nb], demb, nb_emb=nb if demb is not None else 0)
+        ops.linear_dgrad(self.dU[:nb], P["fc.1.weight"], self.dH[:nb])
+        ops.meanT_bwd(self.dH[:nb], self.dZ3[:nb], gref=self.A3[:nb], gact=ACT_LRELU)
+        ops.conv1d_dgrad(self.dZ3[:nb], P["conv.4.weight"], self.dZ2[:nb], 2, gref=self.A2[:nb], gact=ACT_LRELU)
+        ops.conv1d_dgrad(self.dZ2[:nb], P["conv.2.weight"], self.dZ1[:nb], 2, gref=self.A1[:nb], gact=ACT_LRELU)
+
+    def fold_ed(self):
+        """Eval-mode BatchNorm of the frozen ED folded with its conv bias into scale/shift (once)."""
+        for i in range(len(self.ed_chans)):
+            pre = f"encoder.conv.{i}.net"
+            ops.bn_fold(self.ED.p[pre + ".1.weight"], self.ED.p[pre + ".1.bias"], self.EDbuf[pre + ".1.running_mean"],
+                        self.EDbuf[pre + ".1.running_var"], self.ED.p[pre + ".0.bias"], self.ed_scale[i], self.ed_shift[i], BN_EPS)
+        self._ed_folded = True
+
+    def _ed_fwd(self, notes: Tensor):
+        """EmotionDiscriminator.forward in eval mode (ed_model.py:63-69,92-95,147-165)."""
+        P = self.ED.p
+        if self.ed_mode == "notes":
+            x = notes
+            for i in range(len(self.ed_chans)):
+                ops.conv1d_fwd(x, P[f"encoder.conv.{i}.net.0.weight"], self.ed_a[i], 1, scale=self.ed_scale[i],
+                               shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+                x = self.ed_a[i]
+            ops.meanT_fwd(x, self.ed_pool)
+            ops.linear_fwd(self.ed_pool, P["encoder.project.weight"], self.ed_proj, bias=P["encoder.project.bias"])
+            feat = self.ed_proj
+        else:
+            feat = self.lat
+        for j in range(len(self.ed_cz)):
+            ops.linear_fwd(feat, P[f"classifier.net.{3 * j}.weight"], self.ed_ca[j], bias=P[f"classifier.net.{3 * j}.bias"],
+                           zout=self.ed_cz[j], act=ACT_GELU)
+            feat = self.ed_ca[j]
+        ops.linear_fwd(feat, P["classifier.head.weight"], self.logits, bias=P["classifier.head.bias"])
+
+    def _ed_bwd(self, dnotes: Tensor):
+        """Input gradient of the frozen ED: dlogits -> dnotes (notes mode) or -> ed_dfeat (latent mode)."""
+        P = self.ED.p
+        n = len(self.ed_cz)
+        g = self.dlogits
+        w = P["classifier.head.weight"]
+        for j in reversed(range(n)):
+            ops.linear_dgrad(g, w, self.ed_dcz[j], gref=self.ed_cz[j], gact=ACT_GELU)
+            g, w = self.ed_dcz[j], P[f"classifier.net.{3 * j}.weight"]
+        if self.ed_mode != "notes":
+            ops.linear_dgrad(g, w, self.ed_dfeat)
+            return
+        ops.linear_dgrad(g, w, self.ed_dproj)
+        ops.linear_dgrad(self.ed_dproj, P["encoder.project.weight"], self.ed_dpool)
+        last = len(self.ed_chans) - 1
+        ops.meanT_bwd(self.ed_dpool, self.ed_dz[last], gref=self.ed_z[last], gact=ACT_GELU, gscale=self.ed_scale[last])
+        for i in range(last, 0, -1):
+            ops.conv1d_dgrad(self.ed_dz[i], P[f"encoder.conv.{i}.net.0.weight"], self.ed_dz[i - 1], 1,
+                             gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1])
+        ops.conv1d_dgrad(self.ed_dz[0], P["encoder.conv.0.net.0.weight"], dnotes, 1)
+
+    # -------------------------------------------------------------------------------------
+    # D-step  (src/gan/train_gan.py:183-205)
+    # -------------------------------------------------------------------------------------
+    def d_backward(self):
+        B = self.B
+        P, G = self.D.p, self.D.g
+        # no_grad: embedding (dropout ON) and fake batch (BN train mode: running stats move)
+        self._e_fwd(train=True)
+        self._g_fwd(self.X0[B:2 * B], train=True)
+        ops.gp_interp(self.X0[:B], self.X0[B:2 * B], self.alpha, self.X0[2 * B:])
+        self._d_fwd(self.X0, 3 * B)
+        # one backward for [real | fake | x_hat] with ds = [-1/B | +1/B | 1]
+        self._d_bwd_input(self.ds_d, 3 * B, None)
+        ops.conv1d_dgrad(self.dZ1[2 * B:], P["conv.0.weight"], self.gx, 2)
+        ops.gp_penalty(self.gx, self.TAN0, self.norms, self.gp, self.lambda_gp)
+        # tangent pass: d(lambda*gp)/d(grad_xhat) pushed forward through the masked linear critic
+        ops.conv1d_fwd(self.TAN0, P["conv.0.weight"], self.TAN1, 2, gref=self.A1[2 * B:], gact=ACT_LRELU)
+        ops.conv1d_fwd(self.TAN1, P["conv.2.weight"], self.TAN2, 2, gref=self.A2[2 * B:], gact=ACT_LRELU)
+        ops.conv1d_fwd(self.TAN2, P["conv.4.weight"], self.TZ3, 2, gref=self.A3[2 * B:], gact=ACT_LRELU)
+        ops.meanT_fwd(self.TZ3, self.ghb)
+        ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[2 * B:], gact=ACT_LRELU)
+        # weight gradients: [real,fake] activations x Wasserstein dZ  +  tangent activations x penalty dZ
+        ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:])
+        ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:])
+        ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:])
+        ops.linear_wgrad(self.H[:2 * B], self.dU[:2 * B], G["fc.1.weight"], self.ghb, self.dU[2 * B:])
+        ops.colsum(self.dZ1[:2 * B], G["conv.0.bias"])
+        ops.colsum(self.dZ2[:2 * B], G["conv.2.bias"])
+        ops.colsum(self.dZ3[:2 * B], G["conv.4.bias"])
+        ops.colsum(self.dU[:2 * B], G["fc.1.bias"])
+        ops.dhead_wgrad(self.ds_d, self.Fh, self.emb, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"], 2 * B, B)
+        ops.wgan_d_loss(self.s, self.gp, self.lambda_gp, self.loss_d_out, B)
+
+    def d_update(self):
+        ops.adam_flat(self.D.data, self.D.grad, self.D.m, self.D.v, self.D.state, self.lr_d, *self.betas,
+                      grad_scale=1.0 / self.world_size)
+
+    # -------------------------------------------------------------------------------------
+    # G-step  (src/gan/train_gan.py:211-251)
+    # -------------------------------------------------------------------------------------
+    def g_backward(self):
+        B = self.B
+        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
+        PE, GEg = self._ep, (lambda k: self.GE.g["E." + k])
+        if not self._ed_folded:
+            self.fold_ed()
+        self._e_fwd(train=True)
+        self._g_fwd(self.notes, train=True)
+        self._d_fwd(self.notes, B)
+        ops.neg_mean(self.s[:B], self.adv)
+        self._ed_fwd(self.notes)
+        ops.softmax_ce(self.logits, self.emot_idx, self.emo, self.dlogits, self.lambda_emo)
+        # ---- input gradients of the two critics ----
+        if self.ed_mode == "notes":
+            self._ed_bwd(self.dnotes)
+            acc = True
+        else:
+            self._ed_bwd(None)
+            acc = False
+        self._d_bwd_input(self.ds_g, B, self.demb)
+        ops.conv1d_dgrad(self.dZ1[:B], self.D.p["conv.0.weight"], self.dnotes, 2, accumulate=acc)
+        # ---- generator backward ----
+        dn = self.dnotes
+        if self.dn_dense is not None:      # zero-padded tail rows carry no gradient (models.py:78-81)
+            ops.copy_cols(self.dnotes.view(B, -1), 0, self.dn_dense.view(B, -1), 0, self.L3 * self.C)
+            dn = self.dn_dense
+        ops.colsum(dn, GG("decoder.deconv.6.bias"))
+        ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"))
+        ops.convT1d_dgrad(dn, PG("decoder.deconv.6.weight"), self.d_ad3)
+        ops.bn_train_bwd(self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, PG("decoder.deconv.4.weight"), self.bn_mean[1],
+                         self.bn_invstd[1], GG("decoder.deconv.4.weight"), GG("decoder.deconv.4.bias"), ACT_RELU)
+        ops.colsum(self.d_zd3, GG("decoder.deconv.3.bias"))
+        ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"))
+        ops.convT1d_dgrad(self.d_zd3, PG("decoder.deconv.3.weight"), self.d_ad0)
+        ops.bn_train_bwd(self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, PG("decoder.deconv.1.weight"), self.bn_mean[0],
+                         self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
+        ops.colsum(self.d_zd0, GG("decoder.deconv.0.bias"))
+        ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"))
+        ops.convT1d_dgrad(self.d_zd0, PG("decoder.deconv.0.weight"), self.d_y0)
+        # (B, red, 256) -> reference (B, 256*red) order, times relu'
+        ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
+        ops.act_bwd(self.d_p2, self.d_p2, gref=self.a_p2, gact=ACT_RELU)
+        ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"))
+        ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
+        ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
+        ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"))
+        ops.colsum(self.d_p0, GG("decoder.pre.0.bias"))
+        ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
+        if self.ed_mode != "notes":
+            ops.axpby(self.ed_dfeat, self.d_lat, 1.0, 1.0)
+        ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"))
+        ops.colsum(self.d_lat, GG("noise_to_latent.net.2.bias"))
+        ops.linear_dgrad(self.d_lat, PG("noise_to_latent.net.2.weight"), self.d_n0, gref=self.a_n0, gact=ACT_RELU)
+        ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"))
+        ops.colsum(self.d_n0, GG("noise_to_latent.net.0.bias"))
+        ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
+        # embedding gradient = generator-input slice + critic-head path, then E_num backward
+        ops.copy_cols(self.d_gin, self.noise_dim, self.demb, 0, self.E, accumulate=True)
+        ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"))
+        ops.colsum(self.demb, GEg("net.7.bias"))
+        ops.linear_dgrad(self.demb, PE("net.7.weight"), self.d_ez2, gref=self.e_z2, gact=ACT_GELU, emul=self.dmask[1])
+        ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"))
+        ops.colsum(self.d_ez2, GEg("net.4.bias"))
+        ops.linear_dgrad(self.d_ez2, PE("net.4.weight"), self.d_ez1, gref=self.e_z1, gact=ACT_GELU, emul=self.dmask[0])
+        ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"))
+        ops.colsum(self.d_ez1, GEg("net.1.bias"))
+        ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
+        ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
+
+    def g_update(self):
+        ops.adam_flat(self.GE.data, self.GE.grad, self.GE.m, self.GE.v, self.GE.state, self.lr_g, *self.betas,
+                      grad_scale=1.0 / self.world_size)
+
+    # -------------------------------------------------------------------------------------
+    # graph capture / replay
+    # -------------------------------------------------------------------------------------
+    def run(self, name: str, use_graph: bool = True):
+        """Run one of d_backward / d_update / g_backward / g_update, replaying its hipGraph when
+        captured (the first call runs eagerly, which also warms every workspace)."""
+        fn = getattr(self, name)
+        if not use_graph:
+            return fn()
+        st = self._graphs.get(name)
+        if st is None:
+            fn()                                  # eager warm-up (allocates workspaces, sets func attrs)
+            self._graphs[name] = "warm"
+            return
+        if st == "warm":
+            if torch.cuda.current_stream() == torch.cuda.default_stream():
+                raise RuntimeError("GanEngine.run: capture needs a non-default stream (use `with torch.cuda.stream(eng.stream)`)")
+            nbt = self.num_batches_tracked
+            torch.cuda.synchronize()
+            g = ops.Graph()
+            g.begin()
+            try:
+                fn()
+            finally:
+                g.end()
+            self.num_batches_tracked = nbt
+            self._graphs[name] = g
+            st = g
+        st.launch()
+        if name in ("d_backward", "g_backward"):
+            self.num_batches_tracked += 1
+
+    # -------------------------------------------------------------------------------------
+    # inference (app.py:92-119: E_num -> G in eval mode)
+    # -------------------------------------------------------------------------------------
+    def generate(self, noise: Tensor, numeric: Tensor, latent: Optional[Tensor] = None) -> Tensor:
+        self.noise.copy_(noise)
+        self.numeric.copy_(numeric)
+        if latent is not None:
+            self.latent.copy_(latent)
+        self._e_fwd(train=False)
+        self._g_fwd(self.notes, train=False)
+        return self.notes
+
+
+# ------------------------------------------------------------------------------------------
+# smoke check used by __graft_entry__.smoke(): one tiny D-step + G-step against the oracle
+# ------------------------------------------------------------------------------------------
+def smoke_check(B: int = 4, T: int = 32, C: int = 4, verbose: bool = True):
+    import os
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import melo_oracle as O          # the checker, never the product path
+    cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+    eng = GanEngine(cfg, ed_cfg, "cuda", B)
+    eng.load_state(S.PE, S.PG, S.BG, S.PD, S.PED, S.BED)
+    real, numeric, latent, emot = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 7)
+    R = O.step_randoms(B, cfg["NOISE_DIM"], seed=1)
+    eng.set_batch(real.cuda(), numeric.cuda(), latent.cuda(), emot.cuda())
+    eng.set_randoms(R["noise_d"].cuda(), [m.cuda() for m in R["dm_d"]], R["alpha"].cuda())
+    eng.d_backward()
+    eng.d_update()
+    eng.set_randoms(R["noise_g"].cuda(), [m.cuda() for m in R["dm_g"]])
+    eng.g_backward()
+    eng.g_update()
+    torch.cuda.synchronize()
+    rd = O.d_step(S, real, latent, numeric, R["noise_d"], R["alpha"], R["dm_d"])
+    rg = O.g_step(S, latent, numeric, emot, R["noise_g"], R["dm_g"])
+    got = (eng.loss_d_out[0].item(), eng.gp.item(), eng.adv.item(), eng.emo.item())
+    ref = (rd["loss_d"].item(), rd["gp"].item(), rg["loss_g_adv"].item(), rg["loss_g_emo"].item())
+    for g_, r_ in zip(got, ref):
+        assert abs(g_ - r_) <= 1e-4 * max(1.0, abs(r_)), (got, ref)
+    torch.testing.assert_close(eng.notes.cpu(), rg["fake"], rtol=1e-3, atol=1e-5)
+    if verbose:
+        print("smoke ok: loss_d/gp/adv/emo", got, "oracle", ref)
