@@ -9,7 +9,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def header_functions():
     src = open(os.path.join(ROOT, "include", "melo_gan_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mg_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
