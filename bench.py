@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: piano-roll samples/sec of the full (1 critic + 1 generator) step of
+Melo-GAN's GAN training hot path (G + D + frozen emotion-D), B=64 per GPU, 128x256 rolls.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one D-step (src/gan/train_gan.py:183-205) + one G-step (:211-251) on one batch of
+synthetic (B, T=256, C=128) rolls resident in HBM, including the per-step device RNG draws,
+the gradient all-reduce (N>1) and both Adam updates.  value = N*B*K / max-over-ranks wall time.
+
+The same JSON line carries
+  roofline     : the dominant kernel SYMBOL (stride-1 K=3 128x128 window-GEMM: ED conv1-3 forward
+                 and data-gradient, 20.9 of the step's 56.9 GFLOP), algorithmic FLOPs / HIP-event
+                 time of exactly those launches, against the dense fp32-MFMA peak (157.3 TFLOP/s);
+  cpu_baseline : the oracle (PyTorch-CPU fp32 restatement of the reference step) timed on this
+                 host's cores on a bounded number of the same steps (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B_PER_GPU, T, C = 64, 256, 128
+DOMINANT = "conv_wgemm_kernel<1,3,false,2,2>"
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
+# conv+linear FLOPs per sample of one (1D+1G) step at cfg2 as the reference executes it
+MFLOP_PER_SAMPLE = 889.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for the roofline leg")
+    return ap.parse_args()
+
+
+class EventHook:
+    """Brackets every launch of the selected kernel symbols with HIP events on the launch stream."""
+
+    def __init__(self, ops, symbols=None):
+        self.ops, self.symbols, self.records = ops, symbols, []
+
+    def __call__(self, symbol, flops):
+        hook = self
+
+        class Ctx:
+            def __enter__(self_c):
+                self_c.on = hook.symbols is None or symbol in hook.symbols
+                if self_c.on:
+                    self_c.e0, self_c.e1 = hook.ops.Event(), hook.ops.Event()
+                    self_c.e0.record()
+                return self_c
+
+            def __exit__(self_c, *a):
+                if self_c.on:
+                    self_c.e1.record()
+                    hook.records.append((symbol, flops, self_c.e0, self_c.e1))
+                return False
+        return Ctx()
+
+    def summary(self):
+        out = {}
+        for sym, fl, e0, e1 in self.records:
+            ms = e0.elapsed_ms(e1)
+            d = out.setdefault(sym, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += ms
+        return out
+
+
+def cpu_baseline(seconds: float):
+    """Oracle (the CPU restatement, pinned to the reference by tests/golden) on the host cores."""
+    from oracle import melo_oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cfg, ed_cfg = O.default_gan_cfg(B_PER_GPU, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "weights_init", seed=42)
+    real, numeric, latent, emot = O.synthetic_batch(B_PER_GPU, T, C, cfg["LATENT_DIM"], 6, 42)
+
+    def one(i):
+        R = O.step_randoms(B_PER_GPU, cfg["NOISE_DIM"], seed=i)
+        O.d_step(S, real, latent, numeric, R["noise_d"], R["alpha"], R["dm_d"])
+        O.g_step(S, latent, numeric, emot, R["noise_g"], R["dm_g"])
+
+    one(0)
+    one(1)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(2 + n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 40:
+            break
+    return dict(value=round(B_PER_GPU * n / el, 2), unit="samples/s", cores=cores, kind="port",
+                sample=f"{n} full (1D+1G) steps of the same B=64, T=256, C=128 workload, fp32, "
+                       f"torch {torch.__version__} CPU, {el:.1f} s")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    from melo_gan_amd.gan.engine import GanEngine
+    from melo_gan_amd.gan.dp import DataParallel
+    from melo_gan_amd.gan.config import default_gan_cfg, default_ed_cfg
+
+    cfg, ed_cfg = default_gan_cfg(B_PER_GPU, T, C), default_ed_cfg(C)
+    eng = GanEngine(cfg, ed_cfg, f"cuda:{local_rank}", B_PER_GPU)
+    eng.init_weights(seed=42)                       # identical on every rank
+    dp = DataParallel(eng, world, dist if world > 1 else None)
+    dp.broadcast_params()
+    # synthetic data resident in HBM: a small pool of per-rank batches (SURVEY 8d recipe)
+    g = torch.Generator().manual_seed(42 + 1000 * rank)
+    pool = []
+    for _ in range(4):
+        real = (torch.rand(B_PER_GPU, T, C, generator=g) * 2 - 1).cuda()
+        numeric = torch.randn(B_PER_GPU, 6, generator=g).cuda()
+        latent = torch.zeros(B_PER_GPU, cfg["LATENT_DIM"]).cuda()
+        emot = torch.randint(0, 4, (B_PER_GPU,), generator=g).cuda()
+        pool.append((real, numeric, latent, emot))
+    torch.manual_seed(1234 + rank)
+    torch.cuda.manual_seed(1234 + rank)
+    use_graph = not args.no_graph
+
+    def step(i):
+        eng.set_batch(*pool[i % len(pool)])
+        eng.draw_randoms(with_alpha=True)
+        eng.run("d_backward", use_graph)
+        dp.allreduce_d()
+        eng.run("d_update", use_graph)
+        eng.draw_randoms(with_alpha=False)
+        eng.run("g_backward", use_graph)
+        dp.allreduce_g()
+        eng.run("g_update", use_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.cuda.stream(eng.stream):
+        for i in range(max(args.warmup, 3 if use_graph else 1)):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+
+        # ---- roofline leg: HIP events around every launch of the dominant kernel symbol ----
+        roof = None
+        if rank == 0:
+            hook = EventHook(ops, {DOMINANT})
+            ops.set_launch_hook(hook)
+            for i in range(args.profile_steps):
+                eng.set_batch(*pool[i % len(pool)])
+                eng.draw_randoms(True)
+                eng.d_backward()
+                eng.d_update()
+                eng.draw_randoms(False)
+                eng.g_backward()
+                eng.g_update()
+            torch.cuda.synchronize()
+            ops.set_launch_hook(None)
+            sm = hook.summary().get(DOMINANT)
+            if sm:
+                achieved = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
+                roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, kernel=DOMINANT,
+                            launches=sm["launches"], avg_us=round(1e3 * sm["ms"] / sm["launches"], 2),
+                            avg_gflop_per_launch=round(sm["flops"] / sm["launches"] / 1e9, 3))
+        loss_d, adv, emo = eng.loss_d_out[0].item(), eng.adv.item(), eng.emo.item()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        value = world * B_PER_GPU * args.steps / el
+        line = {
+            "metric": "piano-roll samples/sec (G+D step), batch=64 128x256 roll",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: 128x256 piano-roll, batch=64 per GPU, full G+D+emotion-D step "
+                                   "(1 critic update incl. gradient penalty + 1 generator update)",
+                       "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
+                       "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2)},
+            "roofline": roof, "cpu_baseline": cpu,
+            "losses": {"loss_d": round(loss_d, 5), "g_adv": round(adv, 5), "g_emo": round(emo, 5)},
+        }
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

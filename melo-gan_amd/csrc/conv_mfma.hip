@@ -33,16 +33,22 @@ struct ConvP {
     mg_epilogue e;
 };
 
-constexpr int BKC = 16;        // channels per LDS chunk
-constexpr int SX = BKC + 1;    // padded LDS row stride of the input window (odd => conflict-free reads)
+// channels per LDS chunk: 16 for K=3/5 taps, 64 for K=1 (Linear layers: fewer, fatter chunks)
+template <int K> struct ChunkOf { static constexpr int value = (K == 1) ? 64 : 16; };
 
 template <int S, int K, bool TR2, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
+    constexpr int BKC = ChunkOf<K>::value;
+    constexpr int SX = BKC + 1;    // padded LDS row stride of the input window (odd => conflict-free reads)
     constexpr int BM = 64 * TM, BN = 64 * TN, SW = BN + 1;
     constexpr int SA = TR2 ? 1 : S;
     constexpr int NR = TR2 ? 3 : K;
     constexpr int NPH = TR2 ? 2 : 1;
     constexpr int PAD = (K - 1) / 2;
+    constexpr int XQ = BKC / 4;                                       // float4 per window row
+    constexpr int MAXX = (((BM - 1) * SA + NR) * XQ + 255) / 256 + 1;  // prefetch registers (float4) for X
+    constexpr int NW4 = BN * BKC * K / 4 / 256;                       // prefetch registers (float4) for W
+    static_assert((BN * BKC * K) % 1024 == 0, "weight slab must split evenly into float4 per thread");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -89,53 +95,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     const bool vec_ok = ((p.Cin & 3) == 0) && ((p.xbs & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
     const bool w_nck = p.w_sc < p.w_sn;   // (c,k) contiguous for a fixed n
 
-    for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
-        __syncthreads();
-        // ---- stage the input window chunk: rows (seg, r) x 16 channels ----
-        if (vec_ok) {
-            for (int idx = tid; idx < nrows * 4; idx += 256) {
-                const int row = idx >> 2, q = idx & 3;
-                const int seg = row / R, r = row - seg * R;
-                const int b = b0 + seg, tin = tin0 + r, c = c0 + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
-                    v = *reinterpret_cast<const float4*>(p.x + (long)b * p.xbs + (long)tin * p.Cin + c);
-                float* d = Xs + row * SX + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
-            for (int idx = tid; idx < nrows * BKC; idx += 256) {
-                const int row = idx >> 4, cl = idx & 15;
-                const int seg = row / R, r = row - seg * R;
-                const int b = b0 + seg, tin = tin0 + r, c = c0 + cl;
-                float v = 0.f;
-                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
-                    v = p.x[(long)b * p.xbs + (long)tin * p.Cin + c];
-                Xs[row * SX + cl] = v;
-            }
-        }
-        // ---- stage the weight slab: [(c_local, k)][n] ----
-        if (w_nck) {
-            for (int e = tid; e < BN * BKC * K; e += 256) {
-                const int n = e / (BKC * K), ck = e - n * (BKC * K);
-                const int c = ck / K, k = ck - c * K;
-                float v = 0.f;
-                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
-                Ws[ck * SW + n] = v;
-            }
-        } else {
-            for (int e = tid; e < BN * BKC * K; e += 256) {
-                const int c = e / (BN * K), nk = e - c * (BN * K);
-                const int n = nk / K, k = nk - n * K;
-                float v = 0.f;
-                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
-                Ws[(c * K + k) * SW + n] = v;
-            }
-        }
-        __syncthreads();
-
-        const int crem = p.Cin - c0;
-        const int nc2 = (crem >= BKC ? BKC : crem + 1) >> 1;
+    // one chunk of MFMAs out of LDS
+    auto compute = [&](int nc2) {
         for (int c2 = 0; c2 < nc2; ++c2) {
             float a[NR][TM], bw[K][TN];
 #pragma unroll
@@ -169,6 +130,146 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                     }
             }
         }
+    };
+
+    // Fast path: every chunk and this block's weight slab are full and 16-B aligned, so the next chunk's
+    // global loads are issued as float4 into registers BEFORE the current chunk's MFMAs and written to LDS
+    // after them -- HBM/L2 latency hides under the matrix pipe.
+    const bool w_aligned = ((((uintptr_t)p.w) & 15) == 0) &&
+                           (w_nck ? (p.w_sc == K && (p.w_sn & 3) == 0) : (p.w_sn == K && (p.w_sc & 3) == 0));
+    const bool fast = vec_ok && w_aligned && (p.Cin % BKC == 0) && (n0 + BN <= p.N) && (nrows * XQ <= 256 * MAXX);
+
+    if (fast) {
+        // chunk-invariant addressing of this thread's prefetch slots
+        long xg[MAXX];   // global element offset (without the chunk's channel offset), -1 => zero fill
+        int xl[MAXX];    // LDS offset, -1 => slot unused
+#pragma unroll
+        for (int j = 0; j < MAXX; ++j) {
+            const int idx = tid + 256 * j;
+            xg[j] = -1;
+            xl[j] = -1;
+            if (idx < nrows * XQ) {
+                const int row = idx / XQ, q = idx - row * XQ;
+                const int seg = row / R, r = row - seg * R;
+                const int b = b0 + seg, tin = tin0 + r;
+                xl[j] = row * SX + 4 * q;
+                if (b < p.B && tin >= 0 && tin < p.Tin) xg[j] = (long)b * p.xbs + (long)tin * p.Cin + 4 * q;
+            }
+        }
+        long wg[NW4];
+        int wl[NW4];
+#pragma unroll
+        for (int j = 0; j < NW4; ++j) {
+            const int e4 = tid + 256 * j;
+            if (w_nck) {
+                constexpr int PER = BKC * K / 4;
+                const int n = e4 / PER, q = e4 - n * PER;
+                wg[j] = (long)(n0 + n) * p.w_sn + 4 * q;     // + c0*K per chunk
+                wl[j] = (4 * q) * SW + n;
+            } else {
+                constexpr int PER = BN * K / 4;
+                const int c = e4 / PER, q = e4 - c * PER;
+                wg[j] = (long)c * p.w_sc + (long)n0 * K + 4 * q;   // + c0*w_sc per chunk
+                wl[j] = c * K * SW + 4 * q;                  // decoded at store time: (c, nk = 4q+i)
+            }
+        }
+        float4 xr[MAXX], wr[NW4];
+        auto load_chunk = [&](int c0) {
+#pragma unroll
+            for (int j = 0; j < MAXX; ++j) {
+                xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xg[j] >= 0) xr[j] = *reinterpret_cast<const float4*>(p.x + xg[j] + c0);
+            }
+            const long woff = w_nck ? (long)c0 * K : (long)c0 * p.w_sc;
+#pragma unroll
+            for (int j = 0; j < NW4; ++j) wr[j] = *reinterpret_cast<const float4*>(p.w + wg[j] + woff);
+        };
+        auto store_chunk = [&]() {
+#pragma unroll
+            for (int j = 0; j < MAXX; ++j) {
+                if (xl[j] >= 0) {
+                    float* d = Xs + xl[j];
+                    d[0] = xr[j].x; d[1] = xr[j].y; d[2] = xr[j].z; d[3] = xr[j].w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NW4; ++j) {
+                const float v[4] = {wr[j].x, wr[j].y, wr[j].z, wr[j].w};
+                if (w_nck) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Ws[wl[j] + i * SW] = v[i];
+                } else {
+                    const int cbase = (wl[j] / (K * SW)) * (K * SW);
+                    const int nk0 = wl[j] - cbase;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int nk = nk0 + i, n = nk / K, k = nk - n * K;
+                        Ws[cbase + k * SW + n] = v[i];
+                    }
+                }
+            }
+        };
+        load_chunk(0);
+        store_chunk();
+        __syncthreads();
+        for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
+            const bool more = c0 + BKC < p.Cin;
+            if (more) load_chunk(c0 + BKC);
+            compute(BKC / 2);
+            __syncthreads();
+            if (more) {
+                store_chunk();
+                __syncthreads();
+            }
+        }
+    } else {
+    for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
+        __syncthreads();
+        // ---- stage the input window chunk: rows (seg, r) x BKC channels ----
+        if (vec_ok) {
+            for (int idx = tid; idx < nrows * XQ; idx += 256) {
+                const int row = idx / XQ, q = idx - row * XQ;
+                const int seg = row / R, r = row - seg * R;
+                const int b = b0 + seg, tin = tin0 + r, c = c0 + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
+                    v = *reinterpret_cast<const float4*>(p.x + (long)b * p.xbs + (long)tin * p.Cin + c);
+                float* d = Xs + row * SX + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < nrows * BKC; idx += 256) {
+                const int row = idx / BKC, cl = idx - row * BKC;
+                const int seg = row / R, r = row - seg * R;
+                const int b = b0 + seg, tin = tin0 + r, c = c0 + cl;
+                float v = 0.f;
+                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
+                    v = p.x[(long)b * p.xbs + (long)tin * p.Cin + c];
+                Xs[row * SX + cl] = v;
+            }
+        }
+        // ---- stage the weight slab: [(c_local, k)][n] ----
+        if (w_nck) {
+            for (int e = tid; e < BN * BKC * K; e += 256) {
+                const int n = e / (BKC * K), ck = e - n * (BKC * K);
+                const int c = ck / K, k = ck - c * K;
+                float v = 0.f;
+                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
+                Ws[ck * SW + n] = v;
+            }
+        } else {
+            for (int e = tid; e < BN * BKC * K; e += 256) {
+                const int c = e / (BN * K), nk = e - c * (BN * K);
+                const int n = nk / K, k = nk - n * K;
+                float v = 0.f;
+                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
+                Ws[(c * K + k) * SW + n] = v;
+            }
+        }
+        __syncthreads();
+        const int crem = p.Cin - c0;
+        compute((crem >= BKC ? BKC : crem + 1) >> 1);
+    }
     }
 
     // ---- epilogue ----
@@ -214,6 +315,7 @@ template <int S, int K, bool TR2, int TM, int TN>
 int launch_cfg(const ConvP& p0, hipStream_t stream) {
     ConvP p = p0;
     constexpr int BM = 64 * TM, BN = 64 * TN, SW = BN + 1;
+    constexpr int BKC = ChunkOf<K>::value, SX = BKC + 1;
     constexpr int SA = TR2 ? 1 : S;
     constexpr int NR = TR2 ? 3 : K;
     int lg = mg_ilog2_ceil(p.Tm);
@@ -245,11 +347,18 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
 }
 
 // choose the big tile when it still gives enough workgroups to cover the 256 CUs
+bool gather_big_tile(long m_total, int N) {
+    const long big_tiles = mg_cdiv(m_total, 128) * mg_cdiv(N, 128);
+    return N > 64 && big_tiles >= 192;
+}
+bool scatter_big_tile(long m_total, int N) {
+    const long big_tiles = mg_cdiv(m_total, 64) * mg_cdiv(N, 128);
+    return N > 64 && big_tiles >= 192;
+}
+
 template <int S, int K>
 int launch_gather(const ConvP& p, hipStream_t stream) {
-    const long m_total = (long)p.B * p.Tm;
-    const long big_tiles = mg_cdiv(m_total, 128) * mg_cdiv(p.N, 128);
-    if (p.N > 64 && big_tiles >= 192) return launch_cfg<S, K, false, 2, 2>(p, stream);
+    if (gather_big_tile((long)p.B * p.Tm, p.N)) return launch_cfg<S, K, false, 2, 2>(p, stream);
     return launch_cfg<S, K, false, 1, 1>(p, stream);
 }
 
@@ -312,8 +421,13 @@ extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int 
     p.w_sn = w_sn; p.w_sc = w_sc; p.flip = 0;
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const long m_total = (long)B * Tin;
-    const long big_tiles = mg_cdiv(m_total, 64) * mg_cdiv(N, 128);
-    if (N > 64 && big_tiles >= 192) return launch_cfg<2, 5, true, 1, 2>(p, s);
+    if (scatter_big_tile((long)B * Tin, N)) return launch_cfg<2, 5, true, 1, 2>(p, s);
     return launch_cfg<2, 5, true, 1, 1>(p, s);
+}
+
+// Which template instantiation a call would launch: returns TM*10+TN of conv_wgemm_kernel<S,K,TR2,TM,TN>
+// (22 = 128x128 tile, 11 = 64x64, 12 = 64x128 two-phase).  m_rows = B*Tout (gather) or B*Tin (scatter2).
+extern "C" int mg_conv_tile_config(long m_rows, int N, int scatter2) {
+    if (scatter2) return scatter_big_tile(m_rows, N) ? 12 : 11;
+    return gather_big_tile(m_rows, N) ? 22 : 11;
 }

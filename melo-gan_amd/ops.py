@@ -54,6 +54,30 @@ def epilogue(out_shape, N, bias=None, scale=None, shift=None, zout=None, act=ACT
                     1 if accumulate else 0)
 
 
+# Optional per-launch observer (bench.py's roofline leg): called as hook(symbol, flops) and must return a
+# context manager that brackets the launch (e.g. with HIP events).  None => zero overhead.
+_launch_hook = None
+
+
+def set_launch_hook(hook):
+    global _launch_hook
+    _launch_hook = hook
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _observe(symbol_fn, flops):
+    if _launch_hook is None:
+        return _NullCtx()
+    return _launch_hook(symbol_fn(), flops)
+
+
 def _numel(shape):
     n = 1
     for s in shape:
@@ -84,8 +108,11 @@ def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_
     e = epilogue((B, Tout, N), N, **epi)
     if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
-    rc = L.load().mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
-                                   Tin * Cin, y.shape[1] * N, C.byref(e), _stream())
+    lib = L.load()
+    sym = lambda: f"conv_wgemm_kernel<{stride},{K},false,{'2,2' if lib.mg_conv_tile_config(B * Tout, N, 0) == 22 else '1,1'}>"  # noqa: E731
+    with _observe(sym, 2.0 * B * Tout * N * Cin * K):
+        rc = lib.mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
+                                  Tin * Cin, y.shape[1] * N, C.byref(e), _stream())
     L.check(rc, "mg_conv1d_gather")
     return y
 
@@ -106,8 +133,11 @@ def conv_scatter2(x: Tensor, w: Tensor, y: Tensor, N: int, w_sn: int, w_sc: int,
     e = epilogue((B, Tout, N), N, **epi)
     if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
-    rc = L.load().mg_conv1d_scatter2(_p(x), _p(w), _p(y), B, Tin, Cin, N, Tout, w_sn, w_sc, Tin * Cin, y.shape[1] * N,
-                                     C.byref(e), _stream())
+    lib = L.load()
+    sym = lambda: f"conv_wgemm_kernel<2,5,true,{'1,2' if lib.mg_conv_tile_config(B * Tin, N, 1) == 12 else '1,1'}>"  # noqa: E731
+    with _observe(sym, 2.0 * B * Tin * N * Cin * 5):
+        rc = lib.mg_conv1d_scatter2(_p(x), _p(w), _p(y), B, Tin, Cin, N, Tout, w_sn, w_sc, Tin * Cin, y.shape[1] * N,
+                                    C.byref(e), _stream())
     L.check(rc, "mg_conv1d_scatter2")
     return y
 
@@ -214,8 +244,9 @@ def wgrad(small: Tensor, large: Tensor, out: Tensor, K: int, stride: int,
         work = workspace(need, small.device, "wgrad")
     if work.numel() * work.element_size() < need:
         raise ValueError("wgrad: workspace too small")
-    rc = lib.mg_wgrad(_p(small), _p(large), nb0, _p(small2), _p(large2), nb1, _p(out), Ts, Tl, A, Bc, K, stride,
-                      _p(work), work.numel() * work.element_size(), _stream())
+    with _observe(lambda: f"wgrad_kernel<{stride},{K}>", 2.0 * (nb0 + nb1) * Ts * A * Bc * K):
+        rc = lib.mg_wgrad(_p(small), _p(large), nb0, _p(small2), _p(large2), nb1, _p(out), Ts, Tl, A, Bc, K, stride,
+                          _p(work), work.numel() * work.element_size(), _stream())
     L.check(rc, "mg_wgrad")
     return out
 
