@@ -91,7 +91,7 @@ int mg_conv1d_scatter2(const float* x, const float* w, float* y,
                        const mg_epilogue* epi, mg_stream_t stream);
 
 /* Which instantiation of conv_wgemm_kernel<S,K,TR2,TM,TN> a call launches: TM*10+TN (22: 128x128 tile,
- * 11: 64x64, 12: 64x128 two-phase).  m_rows = B*Tout (gather) or B*Tin (scatter2).  Lets a profiler label
+ * 12: 64x128, 11: 64x64).  m_rows = B*Tout (gather) or B*Tin (scatter2).  Lets a profiler label
  * launches by kernel symbol. */
 int mg_conv_tile_config(long m_rows, int N, int scatter2);
 

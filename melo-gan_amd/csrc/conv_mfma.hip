@@ -20,12 +20,15 @@
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 struct ConvP {
     const float* x;
     const float* w;
     float* y;
     int B, Tin, Cin, Tm, Tout, N;
     long xbs, ybs;
+    long x_bytes;    // extent of x in bytes if < 2^31 (buffer-descriptor range), else 0 => slow path
     int w_sn, w_sc;
     int flip;
     int tt_log2;
@@ -59,8 +62,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     const int TB = BM >> p.tt_log2;
     const int R = (TT - 1) * SA + NR;
     const int nrows = TB * R;
+    const int xs_floats = (nrows * SX + 3) & ~3;
+    const int buf_floats = xs_floats + BKC * K * SW;     // one {X window, W slab} buffer; two are allocated
     float* Xs = smem;
-    float* Ws = smem + ((nrows * SX + 3) & ~3);
+    float* Ws = smem + xs_floats;
 
     const int mtile = blockIdx.x;
     const int b0 = (mtile / p.n_ttiles) * TB;
@@ -96,38 +101,64 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     const bool w_nck = p.w_sc < p.w_sn;   // (c,k) contiguous for a fixed n
 
     // one chunk of MFMAs out of LDS
-    auto compute = [&](int nc2) {
-        for (int c2 = 0; c2 < nc2; ++c2) {
-            float a[NR][TM], bw[K][TN];
+    // One chunk of MFMAs out of LDS.  The operand fragments of step c2+1 are read into a second
+    // register set BEFORE the MFMAs of step c2 issue, so the ~100-cycle ds_read latency hides under
+    // the matrix pipe even with a single wave per SIMD (without this, PMC showed 40 % of wave time
+    // parked in s_waitcnt lgkmcnt and the MFMA pipe only 33 % busy).
+    auto frag_load = [&](const float* Xb, const float* Wb, int c2, float (&a)[NR][TM], float (&bw)[K][TN]) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) a[r][mi] = Xs[abase[mi] + r * SX + 2 * c2];
+            for (int mi = 0; mi < TM; ++mi) a[r][mi] = Xb[abase[mi] + r * SX + 2 * c2];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) bw[k][ni] = Wb[bbase[ni] + 2 * c2 * K * SW + kbase + k * kstep];
+    };
+    auto frag_mma = [&](const float (&a)[NR][TM], const float (&bw)[K][TN]) {
+        if constexpr (!TR2) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) bw[k][ni] = Ws[bbase[ni] + 2 * c2 * K * SW + kbase + k * kstep];
-            if constexpr (!TR2) {
-#pragma unroll
-                for (int k = 0; k < K; ++k)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mi], bw[k][ni], acc[0][mi][ni], 0, 0, 0);
-            } else {
-                // phase 0 (t = 2u):   k=0 <- row u+1, k=2 <- row u, k=4 <- row u-1
-                // phase 1 (t = 2u+1): k=1 <- row u+1, k=3 <- row u
-#pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni) {
-                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[0][ni], acc[0][mi][ni], 0, 0, 0);
-                        acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[1][ni], acc[1][mi][ni], 0, 0, 0);
-                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[2][ni], acc[0][mi][ni], 0, 0, 0);
-                        acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[3][ni], acc[1][mi][ni], 0, 0, 0);
-                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][mi], bw[4][ni], acc[0][mi][ni], 0, 0, 0);
-                    }
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mi], bw[k][ni], acc[0][mi][ni], 0, 0, 0);
+        } else {
+            // phase 0 (t = 2u):   k=0 <- row u+1, k=2 <- row u, k=4 <- row u-1
+            // phase 1 (t = 2u+1): k=1 <- row u+1, k=3 <- row u
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[0][ni], acc[0][mi][ni], 0, 0, 0);
+                    acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[1][ni], acc[1][mi][ni], 0, 0, 0);
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[2][ni], acc[0][mi][ni], 0, 0, 0);
+                    acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[3][ni], acc[1][mi][ni], 0, 0, 0);
+                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][mi], bw[4][ni], acc[0][mi][ni], 0, 0, 0);
+                }
+        }
+    };
+    constexpr bool FRAG_DB = !(K == 5 && TM * TN >= 2);   // the 5-tap wide tiles have no registers left for it
+    auto compute = [&](int nc2, int boff) {
+        const float* Xb = Xs + boff;
+        const float* Wb = Ws + boff;
+        if constexpr (FRAG_DB) {
+            float a0[NR][TM], b0[K][TN], a1[NR][TM], b1[K][TN];
+            frag_load(Xb, Wb, 0, a0, b0);
+            int c2 = 0;
+            for (; c2 + 2 <= nc2; c2 += 2) {
+                frag_load(Xb, Wb, c2 + 1, a1, b1);
+                frag_mma(a0, b0);
+                if (c2 + 2 < nc2) frag_load(Xb, Wb, c2 + 2, a0, b0);
+                frag_mma(a1, b1);
+            }
+            if (c2 < nc2) frag_mma(a0, b0);
+        } else {
+            for (int c2 = 0; c2 < nc2; ++c2) {
+                float a0[NR][TM], b0[K][TN];
+                frag_load(Xb, Wb, c2, a0, b0);
+                frag_mma(a0, b0);
             }
         }
     };
@@ -137,23 +168,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     // after them -- HBM/L2 latency hides under the matrix pipe.
     const bool w_aligned = ((((uintptr_t)p.w) & 15) == 0) &&
                            (w_nck ? (p.w_sc == K && (p.w_sn & 3) == 0) : (p.w_sn == K && (p.w_sc & 3) == 0));
-    const bool fast = vec_ok && w_aligned && (p.Cin % BKC == 0) && (n0 + BN <= p.N) && (nrows * XQ <= 256 * MAXX);
+    const bool fast = vec_ok && w_aligned && (p.Cin % BKC == 0) && (n0 + BN <= p.N) && (nrows * XQ <= 256 * MAXX) &&
+                      p.x_bytes > 0;
 
     if (fast) {
         // chunk-invariant addressing of this thread's prefetch slots
-        long xg[MAXX];   // global element offset (without the chunk's channel offset), -1 => zero fill
-        int xl[MAXX];    // LDS offset, -1 => slot unused
+        // X loads go through a raw buffer descriptor: slots of out-of-range rows carry an offset beyond
+        // num_records, for which the hardware returns 0 -- no predicated load (hipcc branches and waits per
+        // slot) and no arithmetic on the loaded registers (hipcc hoists it above the MFMAs and waits there).
+        const __amdgpu_buffer_rsrc_t xrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+        unsigned xo[MAXX];   // byte offset of the slot's float4 (without the chunk's channel offset)
+        int xl[MAXX];        // LDS offset, -1 => slot unused
 #pragma unroll
         for (int j = 0; j < MAXX; ++j) {
             const int idx = tid + 256 * j;
-            xg[j] = -1;
+            xo[j] = 0x80000000u;
             xl[j] = -1;
             if (idx < nrows * XQ) {
                 const int row = idx / XQ, q = idx - row * XQ;
                 const int seg = row / R, r = row - seg * R;
                 const int b = b0 + seg, tin = tin0 + r;
                 xl[j] = row * SX + 4 * q;
-                if (b < p.B && tin >= 0 && tin < p.Tin) xg[j] = (long)b * p.xbs + (long)tin * p.Cin + 4 * q;
+                if (b < p.B && tin >= 0 && tin < p.Tin)
+                    xo[j] = (unsigned)(((long)b * p.xbs + (long)tin * p.Cin + 4 * q) * 4);
             }
         }
         long wg[NW4];
@@ -177,18 +215,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         auto load_chunk = [&](int c0) {
 #pragma unroll
             for (int j = 0; j < MAXX; ++j) {
-                xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (xg[j] >= 0) xr[j] = *reinterpret_cast<const float4*>(p.x + xg[j] + c0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo[j] + 4u * (unsigned)c0, 0, 0);
+                xr[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
             const long woff = w_nck ? (long)c0 * K : (long)c0 * p.w_sc;
 #pragma unroll
             for (int j = 0; j < NW4; ++j) wr[j] = *reinterpret_cast<const float4*>(p.w + wg[j] + woff);
         };
-        auto store_chunk = [&]() {
+        auto store_chunk = [&](int boff) {
+            float* Xb = Xs + boff;
+            float* Wb = Ws + boff;
 #pragma unroll
             for (int j = 0; j < MAXX; ++j) {
                 if (xl[j] >= 0) {
-                    float* d = Xs + xl[j];
+                    float* d = Xb + xl[j];
                     d[0] = xr[j].x; d[1] = xr[j].y; d[2] = xr[j].z; d[3] = xr[j].w;
                 }
             }
@@ -197,30 +237,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                 const float v[4] = {wr[j].x, wr[j].y, wr[j].z, wr[j].w};
                 if (w_nck) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) Ws[wl[j] + i * SW] = v[i];
+                    for (int i = 0; i < 4; ++i) Wb[wl[j] + i * SW] = v[i];
                 } else {
                     const int cbase = (wl[j] / (K * SW)) * (K * SW);
                     const int nk0 = wl[j] - cbase;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int nk = nk0 + i, n = nk / K, k = nk - n * K;
-                        Ws[cbase + k * SW + n] = v[i];
+                        Wb[cbase + k * SW + n] = v[i];
                     }
                 }
             }
         };
+        // double-buffered LDS: chunk i+1 is written to the other buffer right after chunk i's MFMAs,
+        // one barrier per chunk
         load_chunk(0);
-        store_chunk();
+        store_chunk(0);
         __syncthreads();
+        int cur = 0;
         for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
             const bool more = c0 + BKC < p.Cin;
             if (more) load_chunk(c0 + BKC);
-            compute(BKC / 2);
+            compute(BKC / 2, cur);
+            if (more) store_chunk(buf_floats - cur);
             __syncthreads();
-            if (more) {
-                store_chunk();
-                __syncthreads();
-            }
+            cur = buf_floats - cur;
         }
     } else {
     for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
@@ -268,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         }
         __syncthreads();
         const int crem = p.Cin - c0;
-        compute((crem >= BKC ? BKC : crem + 1) >> 1);
+        compute((crem >= BKC ? BKC : crem + 1) >> 1, 0);
     }
     }
 
@@ -325,7 +366,7 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     const int TT = 1 << lg, TB = BM >> lg;
     p.n_ttiles = (int)mg_cdiv(p.Tm, TT);
     const int R = (TT - 1) * SA + NR;
-    const size_t lds = ((size_t)((TB * R * SX + 3) & ~3) + (size_t)BKC * K * SW) * sizeof(float);
+    const size_t lds = 2 * ((size_t)((TB * R * SX + 3) & ~3) + (size_t)BKC * K * SW) * sizeof(float);
     if (lds > 160 * 1024) {
         mg_set_error("conv_wgemm: LDS request %zu too large", lds);
         return MG_EUNSUP;
@@ -346,20 +387,28 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     return MG_OK;
 }
 
-// choose the big tile when it still gives enough workgroups to cover the 256 CUs
-bool gather_big_tile(long m_total, int N) {
-    const long big_tiles = mg_cdiv(m_total, 128) * mg_cdiv(N, 128);
-    return N > 64 && big_tiles >= 192;
+// Tile choice.  The fp32 matrix pipe needs >= 2 waves per SIMD to cover LDS/barrier bubbles (measured: the
+// 128x128 tile at 1 workgroup/CU reaches 68 TFLOP/s, at >= 2/CU 93-100), so a tile is only taken if it still
+// yields ~2 workgroups per CU; otherwise the next smaller one.  Returns TM*10+TN.
+int gather_tile(long m_total, int N) {
+    if (N > 64) {
+        if (mg_cdiv(m_total, 128) * mg_cdiv(N, 128) >= 512) return 22;
+        if (mg_cdiv(m_total, 64) * mg_cdiv(N, 128) >= 384) return 12;
+    }
+    return 11;
 }
-bool scatter_big_tile(long m_total, int N) {
-    const long big_tiles = mg_cdiv(m_total, 64) * mg_cdiv(N, 128);
-    return N > 64 && big_tiles >= 192;
+int scatter_tile(long m_total, int N) {
+    if (N > 64 && mg_cdiv(m_total, 64) * mg_cdiv(N, 128) >= 384) return 12;
+    return 11;
 }
 
 template <int S, int K>
 int launch_gather(const ConvP& p, hipStream_t stream) {
-    if (gather_big_tile((long)p.B * p.Tm, p.N)) return launch_cfg<S, K, false, 2, 2>(p, stream);
-    return launch_cfg<S, K, false, 1, 1>(p, stream);
+    switch (gather_tile((long)p.B * p.Tm, p.N)) {
+        case 22: return launch_cfg<S, K, false, 2, 2>(p, stream);
+        case 12: return launch_cfg<S, K, false, 1, 2>(p, stream);
+        default: return launch_cfg<S, K, false, 1, 1>(p, stream);
+    }
 }
 
 int fill_epilogue(ConvP& p, const mg_epilogue* epi) {
@@ -395,6 +444,7 @@ extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B,
     p.xbs = xbs ? xbs : (long)Tin * Cin;
     p.ybs = ybs ? ybs : (long)Tout * N;
     p.w_sn = w_sn; p.w_sc = w_sc; p.flip = flip;
+    { const long xb = ((long)(B - 1) * p.xbs + (long)Tin * Cin) * 4; p.x_bytes = xb < (1L << 31) ? xb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (stride == 1) {
@@ -419,15 +469,15 @@ extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int 
     p.xbs = xbs ? xbs : (long)Tin * Cin;
     p.ybs = ybs ? ybs : (long)p.Tout * N;
     p.w_sn = w_sn; p.w_sc = w_sc; p.flip = 0;
+    { const long xb = ((long)(B - 1) * p.xbs + (long)Tin * Cin) * 4; p.x_bytes = xb < (1L << 31) ? xb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (scatter_big_tile((long)B * Tin, N)) return launch_cfg<2, 5, true, 1, 2>(p, s);
+    if (scatter_tile((long)B * Tin, N) == 12) return launch_cfg<2, 5, true, 1, 2>(p, s);
     return launch_cfg<2, 5, true, 1, 1>(p, s);
 }
 
 // Which template instantiation a call would launch: returns TM*10+TN of conv_wgemm_kernel<S,K,TR2,TM,TN>
 // (22 = 128x128 tile, 11 = 64x64, 12 = 64x128 two-phase).  m_rows = B*Tout (gather) or B*Tin (scatter2).
 extern "C" int mg_conv_tile_config(long m_rows, int N, int scatter2) {
-    if (scatter2) return scatter_big_tile(m_rows, N) ? 12 : 11;
-    return gather_big_tile(m_rows, N) ? 22 : 11;
+    return scatter2 ? scatter_tile(m_rows, N) : gather_tile(m_rows, N);
 }

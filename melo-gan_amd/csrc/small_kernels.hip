@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int RED_SPLITS = 128;  // max row slices for two-stage column reductions
+constexpr int RED_SPLITS = 32;   // max row slices for two-stage column reductions
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 struct RedPlan { int nsplit; long rows_per; };
 RedPlan red_plan(long R) {
     RedPlan p;
-    long ns = mg_cdiv(R, 64);
+    long ns = mg_cdiv(R, 128);
     if (ns > RED_SPLITS) ns = RED_SPLITS;
     if (ns < 1) ns = 1;
     p.rows_per = mg_cdiv(R, ns);
@@ -80,28 +80,46 @@ RedPlan red_plan(long R) {
     return p;
 }
 
-__global__ void colsum_final_kernel(const double* __restrict__ part, int nsplit, int C, float* sum, float* sumsq) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nsplit; ++k) {
-        s1 += part[((long)k * 2) * C + c];
-        if (sumsq) s2 += part[((long)k * 2 + 1) * C + c];
-    }
+// Final stage of the two-stage reductions: 64 channels x 4 groups per block; group g sums partial
+// slices g, g+4, ... and the four group sums are combined through LDS (<= 8 dependent loads per
+// thread instead of one serial chain over all slices).
+__device__ __forceinline__ bool reduce_partials(const double* __restrict__ part, int nsplit, int C, bool want2,
+                                                double& s1, double& s2, int& c_out) {
+    __shared__ double sh[2][4][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = g; k < nsplit; k += 4) {
+            a += part[((long)k * 2) * C + c];
+            if (want2) b += part[((long)k * 2 + 1) * C + c];
+        }
+    sh[0][g][cx] = a;
+    sh[1][g][cx] = b;
+    __syncthreads();
+    c_out = c;
+    if (g != 0 || c >= C) return false;
+    s1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+    s2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+    return true;
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, int nsplit, int C,
+                                                           float* sum, float* sumsq) {
+    double s1, s2;
+    int c;
+    if (!reduce_partials(part, nsplit, C, sumsq != nullptr, s1, s2, c)) return;
     sum[c] = (float)s1;
     if (sumsq) sumsq[c] = (float)s2;
 }
 
-__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nsplit, int C, long R, float momentum,
-                                      float eps, float* running_mean, float* running_var, float* save_mean,
-                                      float* save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nsplit; ++k) {
-        s1 += part[((long)k * 2) * C + c];
-        s2 += part[((long)k * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nsplit, int C,
+                                                             long R, float momentum, float eps, float* running_mean,
+                                                             float* running_var, float* save_mean,
+                                                             float* save_invstd) {
+    double s1, s2;
+    int c;
+    if (!reduce_partials(part, nsplit, C, true, s1, s2, c)) return;
     const double mean = s1 / (double)R;
     double var = s2 / (double)R - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -144,15 +162,11 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] + ((cb ? cb[c] : 0.f) - rm[c]) * s;
 }
 
-__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nsplit, int C, float* dgamma, float* dbeta,
-                                    double* sums /* [2][C] */) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nsplit; ++k) {
-        s1 += part[((long)k * 2) * C + c];
-        s2 += part[((long)k * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int nsplit, int C,
+                                                           float* dgamma, float* dbeta, double* sums /* [2][C] */) {
+    double s1, s2;
+    int c;
+    if (!reduce_partials(part, nsplit, C, true, s1, s2, c)) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     sums[c] = s1;
@@ -521,7 +535,7 @@ int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq, void* wor
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, x, nullptr, nullptr, nullptr, nullptr, 0, R, C,
                        pl.rows_per, (double*)work, sumsq ? 1 : 0);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, sum, sumsq);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nblk(C, 64)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, sum, sumsq);
     MG_CHECK_LAUNCH("colsum");
     return MG_OK;
 }
@@ -536,7 +550,7 @@ int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma,
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, z, nullptr, nullptr, nullptr, nullptr, 0, R, C,
                        pl.rows_per, (double*)work, 1);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, R,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C, 64)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, R,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, z, a, R * C, C, gamma, beta, save_mean,
                        save_invstd, act);
@@ -555,7 +569,7 @@ int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, 
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), 0, ST, da, a, z, save_mean, save_invstd, act, R, C,
                        pl.rows_per, part, 1);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C)), dim3(256), 0, ST, (const double*)part, pl.nsplit, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C, 64)), dim3(256), 0, ST, (const double*)part, pl.nsplit, C, dgamma,
                        dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, da, a, z, dz, R * C, C, R, gamma,
                        save_mean, save_invstd, (const double*)sums, act);

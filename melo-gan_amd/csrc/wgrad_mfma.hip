@@ -132,12 +132,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     }
 }
 
-__global__ void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, long n, int nsplit) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_z part[z][i]; 64 elements x 4 slice-groups per block (fixed summation order => reproducible)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                           long n, int nsplit) {
+    __shared__ float sh[4][64];
+    const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + ex;
     float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += part[(long)z * n + i];
-    out[i] = s;
+    if (i < n)
+        for (int z = g; z < nsplit; z += 4) s += part[(long)z * n + i];
+    sh[g][ex] = s;
+    __syncthreads();
+    if (g == 0 && i < n) out[i] = (sh[0][ex] + sh[1][ex]) + (sh[2][ex] + sh[3][ex]);
 }
 
 struct Plan {
@@ -216,7 +222,7 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     }
 #undef MG_WG
     MG_CHECK_LAUNCH("wgrad_kernel");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(slab, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(slab, 64)), dim3(256), 0, st,
                        (const float*)work, out, slab, pl.nsplit);
     MG_CHECK_LAUNCH("reduce_slabs_kernel");
     return MG_OK;

@@ -109,7 +109,8 @@ def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_
     if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
     lib = L.load()
-    sym = lambda: f"conv_wgemm_kernel<{stride},{K},false,{'2,2' if lib.mg_conv_tile_config(B * Tout, N, 0) == 22 else '1,1'}>"  # noqa: E731
+    sym = lambda: "conv_wgemm_kernel<%d,%d,false,%s>" % (  # noqa: E731
+        stride, K, {22: "2,2", 12: "1,2", 11: "1,1"}[lib.mg_conv_tile_config(B * Tout, N, 0)])
     with _observe(sym, 2.0 * B * Tout * N * Cin * K):
         rc = lib.mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
                                   Tin * Cin, y.shape[1] * N, C.byref(e), _stream())
