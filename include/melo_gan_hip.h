@@ -90,6 +90,15 @@ int mg_conv1d_scatter2(const float* x, const float* w, float* y,
                        int w_sn, int w_sc, long xbs, long ybs,
                        const mg_epilogue* epi, mg_stream_t stream);
 
+/* ---- skinny GEMM for nn.Linear forward / data-gradient with few rows (M = batch) ----
+ *   y[M,N] = EPI( x[M,K] @ W^T ),  W(n,c) = w[n*w_sn + c*w_sc], one of the strides must be 1:
+ *   nn.Linear forward (src/gan/models.py:24-26,47-49,151; feature_encoder.py:23,38; ed_model.py:61,78,90):
+ *       w (out,in): w_sn = in, w_sc = 1;   data-gradient dx = dy @ w: w_sn = 1, w_sc = in(=N).
+ *   Deep K is split over workgroups into partial slabs in `work` (mg_linear_workspace_bytes, may be 0). */
+size_t mg_linear_workspace_bytes(int M, int N, int K);
+int mg_linear(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, int w_sc,
+              const mg_epilogue* epi, void* work, size_t work_bytes, mg_stream_t stream);
+
 /* Which instantiation of conv_wgemm_kernel<S,K,TR2,TM,TN> a call launches: TM*10+TN (22: 128x128 tile,
  * 12: 64x128, 11: 64x64).  m_rows = B*Tout (gather) or B*Tin (scatter2).  Lets a profiler label
  * launches by kernel symbol. */

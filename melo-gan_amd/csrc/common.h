@@ -69,6 +69,19 @@ __device__ __forceinline__ float mg_act_grad(int gact, float r) {
     }
 }
 
+// The fused epilogue of include/melo_gan_hip.h applied to one accumulator value; di = dense output index,
+// n = output channel.  The caller handles `accumulate` and the final store.
+__device__ __forceinline__ float mg_apply_epilogue(const mg_epilogue& E, float v, int n, long di) {
+    if (E.bias) v += E.bias[n];
+    if (E.scale) v = v * E.scale[n] + E.shift[n];
+    if (E.zout) E.zout[di] = v;
+    v = mg_act(E.act, v);
+    if (E.gref) v *= mg_act_grad(E.gact, E.gref[di]);
+    if (E.emul) v *= E.emul[di];
+    if (E.gscale) v *= E.gscale[n];
+    return v;
+}
+
 static inline int mg_ilog2_ceil(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

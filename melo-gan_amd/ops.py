@@ -180,22 +180,48 @@ def convT1d_dgrad(dy, w, dx, **epi):
     return conv_gather(dy, w, dx, Cin, K, 2, Cout * K, K, **epi)
 
 
+SKINNY_MAX_ROWS = 512      # Linear layers with at most this many rows use the skinny-GEMM kernel
+
+
+def _linear(x, w, y, K, N, w_sn, w_sc, epi):
+    M = x.shape[0]
+    e = epilogue((M, N), N, **epi)
+    lib = L.load()
+    need = lib.mg_linear_workspace_bytes(M, N, K)
+    work = workspace(need, x.device, "linear") if need else None
+    with _observe(lambda: "linear_skinny_kernel", 2.0 * M * N * K):
+        rc = lib.mg_linear(_p(x), _p(w), _p(y), M, K, N, w_sn, w_sc, C.byref(e), _p(work),
+                           work.numel() if work is not None else 0, _stream())
+    L.check(rc, "mg_linear")
+    return y
+
+
 def linear_fwd(x, w, y, **epi):
     """nn.Linear forward; x: (B, in), w: (out, in), y: (B, out)."""
+    _chk(x, "x")
+    _chk(w, "w")
+    _chk(y, "y")
     out_f, in_f = w.shape
     B = x.shape[0]
-    if x.shape[1] != in_f or tuple(y.shape) != (B, out_f):
+    if x.dim() != 2 or x.shape[1] != in_f or tuple(y.shape) != (B, out_f):
         raise ValueError(f"linear_fwd: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)}")
+    if B <= SKINNY_MAX_ROWS:
+        return _linear(x, w, y, in_f, out_f, in_f, 1, epi)
     conv_gather(x.view(B, 1, in_f), w, y.view(B, 1, out_f), out_f, 1, 1, in_f, 1, **epi)
     return y
 
 
 def linear_dgrad(dy, w, dx, **epi):
     """dx = dy @ w; dy: (B, out), w: (out, in), dx: (B, in)."""
+    _chk(dy, "dy")
+    _chk(w, "w")
+    _chk(dx, "dx")
     out_f, in_f = w.shape
     B = dy.shape[0]
-    if dy.shape[1] != out_f or tuple(dx.shape) != (B, in_f):
+    if dy.dim() != 2 or dy.shape[1] != out_f or tuple(dx.shape) != (B, in_f):
         raise ValueError("linear_dgrad: shape mismatch")
+    if B <= SKINNY_MAX_ROWS:
+        return _linear(dy, w, dx, out_f, in_f, 1, in_f, epi)
     conv_gather(dy.view(B, 1, out_f), w, dx.view(B, 1, in_f), in_f, 1, 1, 1, in_f, **epi)
     return dx
 
