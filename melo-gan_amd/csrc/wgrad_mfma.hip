@@ -23,21 +23,27 @@ struct WgradP {
     int n_bgroups;  // total batch groups (over both segments)
     int nbg0;       // batch groups in segment 0
     long slab;      // A*Bc*K
+    int vec_ok;     // all four tensors 16-byte aligned and < 2 GiB (raw-buffer float4 path)
 };
 
 constexpr int RT = 32;   // reduction rows per LDS chunk
 constexpr int BA = 64, BB = 64;
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int S, int K>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     constexpr int PAD = (K - 1) / 2;
+    constexpr int RMAX = (RT - 1) * S + K;                 // L-window rows when one batch fills the chunk
+    constexpr int NS4 = RT * (BA / 4) / 256;               // float4 prefetch slots for S  (= 2)
+    constexpr int NL4 = (RMAX * (BB / 4) + 255) / 256 + 1; // float4 prefetch slots for L
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int TT = 1 << p.tt_log2, TB = RT >> p.tt_log2;
     const int R = (TT - 1) * S + K;
-    float* Ss = smem;                 // [RT][BA]
-    float* Ls = smem + RT * BA;       // [TB*R][BB]
+    const int lrows = TB * R;
+    const int buf_floats = RT * BA + lrows * BB;           // {S rows, L window}; two buffers are allocated
     const int a0 = blockIdx.x * BA, b0 = blockIdx.y * BB;
     const int split = blockIdx.z;
 
@@ -50,9 +56,91 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     const int h = lane >> 5;
     const int g_begin = split * p.bps;
     const int g_end = min(g_begin + p.bps, p.n_bgroups);
-    const bool vecS = ((p.A & 3) == 0) && ((((uintptr_t)p.s[0]) & 15) == 0) && (p.nb[1] == 0 || (((uintptr_t)p.s[1]) & 15) == 0);
-    const bool vecL = ((p.Bc & 3) == 0) && ((((uintptr_t)p.l[0]) & 15) == 0) && (p.nb[1] == 0 || (((uintptr_t)p.l[1]) & 15) == 0);
+    const int n_chunks = (g_end - g_begin) * p.n_ttiles;
 
+    auto compute = [&](int boff) {
+        const float* Ss = smem + boff;
+        const float* Ls = Ss + RT * BA;
+#pragma unroll
+        for (int r2 = 0; r2 < RT / 2; ++r2) {
+            const int r = 2 * r2 + h;
+            const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+            const float av = Ss[r * BA + wa * 32 + (lane & 31)];
+            const float* lrow = Ls + (seg * R + tl * S) * BB + wb * 32 + (lane & 31);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lrow[k * BB], acc[k], 0, 0, 0);
+        }
+    };
+
+    const bool fast = ((p.A & 3) == 0) && ((p.Bc & 3) == 0) && p.vec_ok && (lrows * (BB / 4) <= 256 * NL4);
+    if (fast) {
+        // Software pipeline as in conv_mfma.hip: the next chunk's S rows and L window are fetched with
+        // raw-buffer float4 loads (out-of-range slots return 0 in hardware) while the current chunk's MFMAs
+        // run out of the other LDS buffer; one barrier per chunk.
+        float4 sr[NS4], lr[NL4];
+        auto load_chunk = [&](int c) {
+            const int g = g_begin + c / p.n_ttiles, tt = c - (c / p.n_ttiles) * p.n_ttiles;
+            const int seg_id = g < p.nbg0 ? 0 : 1;
+            const int bg = seg_id ? g - p.nbg0 : g;
+            const int nb = p.nb[seg_id];
+            const int bb0 = bg * TB, t0 = tt * TT, tl0 = t0 * S - PAD;
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(seg_id ? p.s[1] : p.s[0]), 0, (int)((long)nb * p.Ts * p.A * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(seg_id ? p.l[1] : p.l[0]), 0, (int)((long)nb * p.Tl * p.Bc * 4), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NS4; ++j) {
+                const int idx = tid + 256 * j;
+                const int r = idx / (BA / 4), q = idx - r * (BA / 4);
+                const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+                const int b = bb0 + seg, t = t0 + tl, a = a0 + 4 * q;
+                unsigned off = 0x80000000u;
+                if (b < nb && t < p.Ts && a < p.A) off = (unsigned)((((long)b * p.Ts + t) * p.A + a) * 4);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, 0);
+                sr[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+#pragma unroll
+            for (int j = 0; j < NL4; ++j) {
+                const int idx = tid + 256 * j;
+                const int row = idx / (BB / 4), q = idx - row * (BB / 4);
+                const int seg = row / R, rr = row - seg * R;
+                const int b = bb0 + seg, t = tl0 + rr, cc = b0 + 4 * q;
+                unsigned off = 0x80000000u;
+                if (row < lrows && b < nb && t >= 0 && t < p.Tl && cc < p.Bc)
+                    off = (unsigned)((((long)b * p.Tl + t) * p.Bc + cc) * 4);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lrs, off, 0, 0);
+                lr[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+        };
+        auto store_chunk = [&](int boff) {
+            float* Ss = smem + boff;
+            float* Ls = Ss + RT * BA;
+#pragma unroll
+            for (int j = 0; j < NS4; ++j) *reinterpret_cast<float4*>(Ss + 4 * (tid + 256 * j)) = sr[j];
+#pragma unroll
+            for (int j = 0; j < NL4; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < lrows * (BB / 4)) *reinterpret_cast<float4*>(Ls + 4 * idx) = lr[j];
+            }
+        };
+        if (n_chunks > 0) {
+            load_chunk(0);
+            store_chunk(0);
+            __syncthreads();
+            int cur = 0;
+            for (int c = 0; c < n_chunks; ++c) {
+                const bool more = c + 1 < n_chunks;
+                if (more) load_chunk(c + 1);
+                compute(cur);
+                if (more) store_chunk(buf_floats - cur);
+                __syncthreads();
+                cur = buf_floats - cur;
+            }
+        }
+    } else {
+    float* Ss = smem;                 // [RT][BA]
+    float* Ls = smem + RT * BA;       // [TB*R][BB]
     for (int g = g_begin; g < g_end; ++g) {
         const int seg_id = g < p.nbg0 ? 0 : 1;
         const int bg = seg_id ? g - p.nbg0 : g;
@@ -64,60 +152,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
             const int t0 = tt * TT;
             const int tl0 = t0 * S - PAD;
             __syncthreads();
-            // S rows: (seg, tl) -> r = seg*TT + tl
-            if (vecS) {
-                for (int idx = tid; idx < RT * (BA / 4); idx += 256) {
-                    const int r = idx / (BA / 4), q = idx - r * (BA / 4);
-                    const int seg = r >> p.tt_log2, tl = r & (TT - 1);
-                    const int b = bb0 + seg, t = t0 + tl, a = a0 + 4 * q;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (b < nb && t < p.Ts && a < p.A)
-                        v = *reinterpret_cast<const float4*>(Sp + ((long)b * p.Ts + t) * p.A + a);
-                    *reinterpret_cast<float4*>(Ss + r * BA + 4 * q) = v;
-                }
-            } else {
-                for (int idx = tid; idx < RT * BA; idx += 256) {
-                    const int r = idx / BA, al = idx - r * BA;
-                    const int seg = r >> p.tt_log2, tl = r & (TT - 1);
-                    const int b = bb0 + seg, t = t0 + tl, a = a0 + al;
-                    float v = 0.f;
-                    if (b < nb && t < p.Ts && a < p.A) v = Sp[((long)b * p.Ts + t) * p.A + a];
-                    Ss[r * BA + al] = v;
-                }
+            for (int idx = tid; idx < RT * BA; idx += 256) {
+                const int r = idx / BA, al = idx - r * BA;
+                const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+                const int b = bb0 + seg, t = t0 + tl, a = a0 + al;
+                float v = 0.f;
+                if (b < nb && t < p.Ts && a < p.A) v = Sp[((long)b * p.Ts + t) * p.A + a];
+                Ss[r * BA + al] = v;
             }
-            // L window rows: (seg, rr), input time tl0 + rr
-            if (vecL) {
-                for (int idx = tid; idx < TB * R * (BB / 4); idx += 256) {
-                    const int row = idx / (BB / 4), q = idx - row * (BB / 4);
-                    const int seg = row / R, rr = row - seg * R;
-                    const int b = bb0 + seg, t = tl0 + rr, c = b0 + 4 * q;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (b < nb && t >= 0 && t < p.Tl && c < p.Bc)
-                        v = *reinterpret_cast<const float4*>(Lp + ((long)b * p.Tl + t) * p.Bc + c);
-                    *reinterpret_cast<float4*>(Ls + row * BB + 4 * q) = v;
-                }
-            } else {
-                for (int idx = tid; idx < TB * R * BB; idx += 256) {
-                    const int row = idx / BB, cl = idx - row * BB;
-                    const int seg = row / R, rr = row - seg * R;
-                    const int b = bb0 + seg, t = tl0 + rr, c = b0 + cl;
-                    float v = 0.f;
-                    if (b < nb && t >= 0 && t < p.Tl && c < p.Bc) v = Lp[((long)b * p.Tl + t) * p.Bc + c];
-                    Ls[row * BB + cl] = v;
-                }
+            for (int idx = tid; idx < TB * R * BB; idx += 256) {
+                const int row = idx / BB, cl = idx - row * BB;
+                const int seg = row / R, rr = row - seg * R;
+                const int b = bb0 + seg, t = tl0 + rr, c = b0 + cl;
+                float v = 0.f;
+                if (b < nb && t >= 0 && t < p.Tl && c < p.Bc) v = Lp[((long)b * p.Tl + t) * p.Bc + c];
+                Ls[row * BB + cl] = v;
             }
             __syncthreads();
-#pragma unroll 4
-            for (int r2 = 0; r2 < RT / 2; ++r2) {
-                const int r = 2 * r2 + h;
-                const int seg = r >> p.tt_log2, tl = r & (TT - 1);
-                const float av = Ss[r * BA + wa * 32 + (lane & 31)];
-                const float* lrow = Ls + (seg * R + tl * S) * BB + wb * 32 + (lane & 31);
-#pragma unroll
-                for (int k = 0; k < K; ++k)
-                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lrow[k * BB], acc[k], 0, 0, 0);
-            }
+            compute(0);
         }
+    }
     }
     float* out = p.part + (long)split * p.slab;
     const int b = b0 + wb * 32 + (lane & 31);
@@ -210,7 +264,12 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     p.slab = slab;
     const int TT = 1 << pl.tt_log2;
     const int R = (TT - 1) * stride + K;
-    const size_t lds = ((size_t)RT * BA + (size_t)pl.TB * R * BB) * sizeof(float);
+    const size_t lds = 2 * ((size_t)RT * BA + (size_t)pl.TB * R * BB) * sizeof(float);
+    {
+        auto ok = [](const float* q, long elems) { return q == nullptr || (((((uintptr_t)q) & 15) == 0) && elems * 4 < (1L << 31)); };
+        p.vec_ok = ok(s0, (long)nb0 * Ts * A) && ok(l0, (long)nb0 * Tl * Bc) && ok(nb1 ? s1 : nullptr, (long)nb1 * Ts * A) &&
+                   ok(nb1 ? l1 : nullptr, (long)nb1 * Tl * Bc);
+    }
     dim3 grid((unsigned)mg_cdiv(A, BA), (unsigned)mg_cdiv(Bc, BB), (unsigned)pl.nsplit);
     hipStream_t st = (hipStream_t)stream;
 #define MG_WG(S_, K_) hipLaunchKernelGGL((wgrad_kernel<S_, K_>), grid, dim3(256), lds, st, p)
