@@ -83,10 +83,24 @@ class EventHook:
         return out
 
 
+def host_cores() -> int:
+    """CPU threads this process may actually use: the cgroup quota if there is one, else the affinity mask,
+    capped at 16 (the GPU box's CPU share per GPU) -- oversubscribing ATen's thread pool is far slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except OSError:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(seconds: float):
     """Oracle (the CPU restatement, pinned to the reference by tests/golden) on the host cores."""
     from oracle import melo_oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg, ed_cfg = O.default_gan_cfg(B_PER_GPU, T, C), O.default_ed_cfg(C)
     S = O.build_gan_state(cfg, ed_cfg, "weights_init", seed=42)
@@ -104,7 +118,7 @@ def cpu_baseline(seconds: float):
         one(2 + n)
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 40:
+        if el >= seconds or n >= 5000:
             break
     return dict(value=round(B_PER_GPU * n / el, 2), unit="samples/s", cores=cores, kind="port",
                 sample=f"{n} full (1D+1G) steps of the same B=64, T=256, C=128 workload, fp32, "
@@ -148,18 +162,15 @@ def main():
         latent = torch.zeros(B_PER_GPU, cfg["LATENT_DIM"]).cuda()
         emot = torch.randint(0, 4, (B_PER_GPU,), generator=g).cuda()
         pool.append((real, numeric, latent, emot))
-    torch.manual_seed(1234 + rank)
-    torch.cuda.manual_seed(1234 + rank)
+    eng.seed(1234 + rank)                            # rank-offset Philox key: every shard draws its own noise
     use_graph = not args.no_graph
 
     def step(i):
         eng.set_batch(*pool[i % len(pool)])
-        eng.draw_randoms(with_alpha=True)
-        eng.run("d_backward", use_graph)
+        eng.run("d_backward_rng", use_graph)      # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
         dp.allreduce_d()
         eng.run("d_update", use_graph)
-        eng.draw_randoms(with_alpha=False)
-        eng.run("g_backward", use_graph)
+        eng.run("g_backward_rng", use_graph)
         dp.allreduce_g()
         eng.run("g_update", use_graph)
 
@@ -192,11 +203,9 @@ def main():
             ops.set_launch_hook(hook)
             for i in range(args.profile_steps):
                 eng.set_batch(*pool[i % len(pool)])
-                eng.draw_randoms(True)
-                eng.d_backward()
+                eng.d_backward_rng()
                 eng.d_update()
-                eng.draw_randoms(False)
-                eng.g_backward()
+                eng.g_backward_rng()
                 eng.g_update()
             torch.cuda.synchronize()
             ops.set_launch_hook(None)

@@ -201,6 +201,14 @@ int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, mg_st
 int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, float* dx, long n,
                mg_stream_t stream);
 
+/* ---- per-step random inputs (replaces torch.randn / torch.rand / nn.Dropout's bernoulli draws:
+ *      src/gan/train_gan.py:188,218; src/gan/utils.py:76; src/gan/feature_encoder.py:34) in ONE launch:
+ *      normal[n_normal] ~ N(0,1), uniform[n_uniform] ~ U(0,1), mask{0,1} = keep-mask * 1/(1-p_drop).
+ *      Philox4x32-10 keyed by `seed`; *step_counter (device, uint64) is read and then advanced on device,
+ *      so a captured hipGraph draws fresh numbers at every replay.  Any pointer may be NULL. */
+int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
+                float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter, mg_stream_t stream);
+
 /* ---- fused flat Adam / AdamW (torch.optim.Adam defaults; src/gan/train_gan.py:136-145,
  *      src/ae/train_ae.py:79).  state: double[4] = {step, beta1^step, beta2^step, unused},
  *      advanced on device so the launch is hipGraph-replayable.  grad_scale multiplies g first

@@ -51,6 +51,7 @@ SIGNATURES = {
     "mg_copy_cols": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
     "mg_transpose_bcl_blc": (i32, [vp, vp, i32, i32, i32, vp]),
     "mg_act_bwd": (i32, [vp, vp, i32, vp, vp, i64, vp]),
+    "mg_rng_fill": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp]),
     "mg_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
     "mg_grad_norm_workspace_bytes": (sz, [i64]),
     "mg_grad_norm_clip": (i32, [vp, i64, f32, vp, vp, sz, vp]),

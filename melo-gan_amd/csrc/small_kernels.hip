@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int RED_SPLITS = 32;   // max row slices for two-stage column reductions
+constexpr int RED_SPLITS = 64;   // max row slices for two-stage column reductions
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -28,6 +28,8 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 // ---------------- column sums: partial[split][{sum,sumsq}][c] ----------------
 // MODE 0: v = x          MODE 1 (BN backward): v1 = dy*mask(a), v2 = v1 * xhat(z)
+// A block covers 64 channels as 16 float4 lanes x 16 row lanes (rows r0+ry, step 16), so even C=64 tensors
+// spread over many blocks (one per row slice) with 16-byte loads; fp64 accumulation is free at HBM-bound rates.
 template <int MODE>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ a,
                                                              const float* __restrict__ z,
@@ -35,44 +37,74 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                              const float* __restrict__ invstd, int act, long R,
                                                              int C, long rows_per, double* __restrict__ part,
                                                              int want_sq) {
-    __shared__ double sh[2][4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double sh[2][16][65];
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 64 + 4 * cq;
     const long r0 = (long)blockIdx.y * rows_per;
     long r1 = r0 + rows_per;
     if (r1 > R) r1 = R;
-    double s1 = 0.0, s2 = 0.0;     // fp64 accumulation is free here: the kernel is HBM-bound
-    if (c < C) {
-        float mu = 0.f, is = 0.f;
-        if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
-        for (long r = r0 + ry; r < r1; r += 4) {
-            const long i = r * C + c;
-            if (MODE == 0) {
-                const double v = (double)x[i];
-                s1 += v;
-                s2 += v * v;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const bool vec = ((C & 3) == 0) && (c0 + 3 < C);
+    if (c0 < C) {
+        float mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+        if (MODE == 1)
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < C) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; }
+        for (long r = r0 + ry; r < r1; r += 16) {
+            const long i = r * C + c0;
+            float xv[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0}, zv[4] = {0, 0, 0, 0};
+            if (vec) {
+                const float4 t = *reinterpret_cast<const float4*>(x + i);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                if (MODE == 1) {
+                    const float4 ta = *reinterpret_cast<const float4*>(a + i);
+                    const float4 tz = *reinterpret_cast<const float4*>(z + i);
+                    av[0] = ta.x; av[1] = ta.y; av[2] = ta.z; av[3] = ta.w;
+                    zv[0] = tz.x; zv[1] = tz.y; zv[2] = tz.z; zv[3] = tz.w;
+                }
             } else {
-                const double dy = (double)(x[i] * mg_act_grad(act, a[i]));
-                s1 += dy;
-                s2 += dy * (((double)z[i] - (double)mu) * (double)is);
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < C) {
+                        xv[e] = x[i + e];
+                        if (MODE == 1) { av[e] = a[i + e]; zv[e] = z[i + e]; }
+                    }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (MODE == 0) {
+                    const double v = (double)xv[e];
+                    s1[e] += v;
+                    s2[e] += v * v;
+                } else {
+                    const double dy = (double)(xv[e] * mg_act_grad(act, av[e]));
+                    s1[e] += dy;
+                    s2[e] += dy * (((double)zv[e] - (double)mu[e]) * (double)is[e]);
+                }
             }
         }
     }
-    sh[0][ry][cx] = s1;
-    sh[1][ry][cx] = s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sh[0][ry][4 * cq + e] = s1[e];
+        sh[1][ry][4 * cq + e] = s2[e];
+    }
     __syncthreads();
-    if (ry == 0 && c < C) {
-        const double t1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
-        const double t2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
-        part[((long)blockIdx.y * 2 + 0) * C + c] = t1;
-        if (want_sq) part[((long)blockIdx.y * 2 + 1) * C + c] = t2;
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6, cx = threadIdx.x & 63;
+        const int c = blockIdx.x * 64 + cx;
+        if (c < C && (w == 0 || want_sq)) {
+            double t = 0.0;
+#pragma unroll
+            for (int y = 0; y < 16; ++y) t += sh[w][y][cx];
+            part[((long)blockIdx.y * 2 + w) * C + c] = t;
+        }
     }
 }
 
 struct RedPlan { int nsplit; long rows_per; };
 RedPlan red_plan(long R) {
     RedPlan p;
-    long ns = mg_cdiv(R, 128);
+    long ns = mg_cdiv(R, 256);
     if (ns > RED_SPLITS) ns = RED_SPLITS;
     if (ns < 1) ns = 1;
     p.rows_per = mg_cdiv(R, ns);
@@ -282,26 +314,27 @@ __global__ void dhead_demb_kernel(const float* __restrict__ ds, const float* __r
     demb[i] = s * w[F + j];
 }
 
+// one wave per output element j: lanes stride over the batch rows, shuffle-reduce
 __global__ void dhead_wgrad_kernel(const float* __restrict__ ds, const float* __restrict__ f,
                                    const float* __restrict__ emb, const float* __restrict__ gf, float* dw,
                                    float* dbias, int nb, int ng, int Be, int F, int E) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
     if (j < F) {
-        float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += ds[b] * f[(long)b * F + j];
-        float g = 0.f;
+        for (int b = lane; b < nb; b += 64) s += ds[b] * f[(long)b * F + j];
         if (gf)
-            for (int b = 0; b < ng; ++b) g += gf[(long)b * F + j];
-        dw[j] = s + g;
+            for (int b = lane; b < ng; b += 64) s += gf[(long)b * F + j];
     } else if (j < F + E) {
-        float s = 0.f;
         if (emb)
-            for (int b = 0; b < nb; ++b) s += ds[b] * emb[(long)(b % Be) * E + (j - F)];
-        dw[j] = s;
+            for (int b = lane; b < nb; b += 64) s += ds[b] * emb[(long)(b % Be) * E + (j - F)];
     } else if (j == F + E) {
-        float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += ds[b];
-        dbias[0] = s;
+        for (int b = lane; b < nb; b += 64) s += ds[b];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (j < F + E) dw[j] = s;
+        else if (j == F + E) dbias[0] = s;
     }
 }
 
@@ -430,6 +463,58 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     if (gref) v *= mg_act_grad(gact, gref[i]);
     if (emul) v *= emul[i];
     dx[i] = v;
+}
+
+// ---------------- per-step random inputs in one launch ----------------
+// Philox4x32-10 counter-based generator.  key = (seed lo, seed hi), counter = (element block, stream id,
+// step lo, step hi); the step counter lives in device memory and is advanced by the kernel itself so a
+// captured hipGraph draws fresh numbers on every replay.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+struct RngJob { float* dst; long n; int kind; float p0; };   // kind 0: N(0,1); 1: U(0,1); 2: keep-mask*(1/(1-p0))
+struct RngJobs { RngJob j[4]; int njobs; };
+
+__global__ void rng_fill_kernel(const RngJobs jobs, unsigned long long seed, unsigned long long* step_ctr) {
+    const unsigned long long step = step_ctr[0];
+    const int jid = blockIdx.y;
+    if (jid < jobs.njobs) {
+        const RngJob jb = jobs.j[jid];
+        for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; 4 * q < jb.n; q += (long)gridDim.x * blockDim.x) {
+            unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32) ^ ((unsigned)jid << 28), (unsigned)step, (unsigned)(step >> 32)};
+            philox4(c, (unsigned)seed, (unsigned)(seed >> 32));
+            float v[4];
+            if (jb.kind == 0) {
+                const float r0 = sqrtf(-2.f * logf(u01(c[0]))), r1 = sqrtf(-2.f * logf(u01(c[2])));
+                const float t0 = 6.28318530717958647692f * u01(c[1]), t1 = 6.28318530717958647692f * u01(c[3]);
+                v[0] = r0 * cosf(t0); v[1] = r0 * sinf(t0); v[2] = r1 * cosf(t1); v[3] = r1 * sinf(t1);
+            } else if (jb.kind == 1) {
+                for (int e = 0; e < 4; ++e) v[e] = u01(c[e]);
+            } else {
+                const float sc = 1.f / (1.f - jb.p0);
+                for (int e = 0; e < 4; ++e) v[e] = u01(c[e]) >= jb.p0 ? sc : 0.f;
+            }
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < jb.n) jb.dst[4 * q + e] = v[e];
+        }
+    }
+}
+__global__ void rng_advance_kernel(unsigned long long* step_ctr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) step_ctr[0] += 1;
 }
 
 // ---------------- Adam ----------------
@@ -649,7 +734,7 @@ int mg_dhead_bwd(const float* ds, const float* f, const float* w, float* dU, flo
 int mg_dhead_wgrad(const float* ds, const float* f, const float* emb, const float* gf, float* dw, float* dbias,
                    int nb, int ng, int Be, int F, int E, mg_stream_t stream) {
     MG_CHECK_ARG(ds && f && dw && dbias, "mg_dhead_wgrad: bad args");
-    hipLaunchKernelGGL(dhead_wgrad_kernel, dim3(nblk(F + E + 1, 64)), dim3(64), 0, ST, ds, f, emb, gf, dw, dbias, nb, ng,
+    hipLaunchKernelGGL(dhead_wgrad_kernel, dim3(nblk(F + E + 1, 4)), dim3(256), 0, ST, ds, f, emb, gf, dw, dbias, nb, ng,
                        Be > 0 ? Be : 1, F, emb ? E : 0);
     MG_CHECK_LAUNCH("dhead_wgrad");
     return MG_OK;
@@ -731,6 +816,31 @@ int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, 
     MG_CHECK_ARG(dy && dx && n > 0, "mg_act_bwd: bad args");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(n)), dim3(256), 0, ST, dy, gref, gact, emul, dx, n);
     MG_CHECK_LAUNCH("act_bwd");
+    return MG_OK;
+}
+
+int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
+                float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter, mg_stream_t stream) {
+    MG_CHECK_ARG(step_counter != nullptr, "mg_rng_fill: null step counter");
+    MG_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mg_rng_fill: bad dropout probability");
+    RngJobs jobs{};
+    int n = 0;
+    long mx = 0;
+    auto add = [&](float* d, long cnt, int kind) {
+        if (d && cnt > 0) { jobs.j[n++] = RngJob{d, cnt, kind, p_drop}; if (cnt > mx) mx = cnt; }
+    };
+    add(normal, n_normal, 0);
+    add(uniform, n_uniform, 1);
+    add(mask0, n_mask0, 2);
+    add(mask1, n_mask1, 2);
+    jobs.njobs = n;
+    if (n == 0) return MG_OK;
+    unsigned gx = (unsigned)mg_cdiv(mg_cdiv(mx, 4), 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(rng_fill_kernel, dim3(gx, n), dim3(256), 0, ST, jobs, (unsigned long long)seed,
+                       (unsigned long long*)step_counter);
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, ST, (unsigned long long*)step_counter);
+    MG_CHECK_LAUNCH("rng_fill");
     return MG_OK;
 }
 

@@ -256,6 +256,8 @@ class GanEngine:
         self.logits, self.dlogits = z(B, self.n_classes), z(B, self.n_classes)
         self.ed_dproj, self.ed_dpool = z(B, hid), z(B, self.ed_pool.shape[1])
         self.ed_dfeat = z(B, self.ed_feat_dim)
+        self.rng_seed = int(cfg.get("SEED", 42))
+        self.rng_step = torch.zeros(1, dtype=torch.int64, device=d)
         self._graphs = {}
         # hipGraph capture is illegal on the null stream: every step runs on this side stream
         self.stream = torch.cuda.Stream(device=d)
@@ -335,13 +337,14 @@ class GanEngine:
                 dst.copy_(m.to(torch.float32) * (1.0 / (1.0 - P_DROP)), non_blocking=True)
 
     def draw_randoms(self, with_alpha: bool):
-        """Production path: device RNG (torch's Philox generator) straight into the static buffers."""
-        self.noise.normal_()
-        if with_alpha:
-            self.alpha.uniform_()
-        for m in self.dmask:
-            m.uniform_()
-            m.copy_((m >= P_DROP).to(torch.float32) * (1.0 / (1.0 - P_DROP)))
+        """Production path: one Philox launch fills noise, alpha and both dropout masks (draw order of the
+        reference per sub-step: dropout masks, randn noise, rand alpha -- SURVEY section 3)."""
+        ops.rng_fill(self.noise, self.alpha if with_alpha else None, self.dmask[0], self.dmask[1], P_DROP,
+                     self.rng_seed, self.rng_step)
+
+    def seed(self, seed: int):
+        self.rng_seed = int(seed)
+        self.rng_step.zero_()
 
     # -------------------------------------------------------------------------------------
     # forward pieces
@@ -491,6 +494,15 @@ class GanEngine:
         ops.dhead_wgrad(self.ds_d, self.Fh, self.emb, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"], 2 * B, B)
         ops.wgan_d_loss(self.s, self.gp, self.lambda_gp, self.loss_d_out, B)
 
+    def d_backward_rng(self):
+        """Production D-step front half: device RNG draw + d_backward as one capturable sequence."""
+        self.draw_randoms(with_alpha=True)
+        self.d_backward()
+
+    def g_backward_rng(self):
+        self.draw_randoms(with_alpha=False)
+        self.g_backward()
+
     def d_update(self):
         ops.adam_flat(self.D.data, self.D.grad, self.D.m, self.D.v, self.D.state, self.lr_d, *self.betas,
                       grad_scale=1.0 / self.world_size)
@@ -600,7 +612,7 @@ class GanEngine:
             self._graphs[name] = g
             st = g
         st.launch()
-        if name in ("d_backward", "g_backward"):
+        if name in ("d_backward", "g_backward", "d_backward_rng", "g_backward_rng"):
             self.num_batches_tracked += 1
 
     # -------------------------------------------------------------------------------------

@@ -559,6 +559,17 @@ def act_bwd(dy, dx, gref=None, gact=ACT_NONE, emul=None):
     L.check(L.load().mg_act_bwd(_p(dy), _p(gref), gact, _p(emul), _p(dx), n, _stream()), "mg_act_bwd")
 
 
+def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter):
+    """One launch: normal ~ N(0,1), uniform ~ U(0,1), mask* = keep-mask/(1-p_drop); any of them may be None."""
+    for t in (normal, uniform, mask0, mask1):
+        if t is not None:
+            _chk(t, "rng tensor")
+    _chk(step_counter, "step_counter", (1,), torch.int64)
+    n = lambda t: 0 if t is None else t.numel()  # noqa: E731
+    L.check(L.load().mg_rng_fill(_p(normal), n(normal), _p(uniform), n(uniform), _p(mask0), n(mask0), _p(mask1),
+                                 n(mask1), p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(step_counter), _stream()), "mg_rng_fill")
+
+
 def adam_flat(p, g, m, v, state, lr, beta1, beta2, eps=1e-8, weight_decay=0.0, grad_scale=1.0, gs_dev=None):
     n = p.numel()
     for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):

@@ -303,3 +303,27 @@ def test_dhead(ops):
     ref[:Fd] += gf.sum(0)
     assert_close(dw, ref, atol=1e-4)
     assert_close(db, ds[:8].sum().reshape(1))
+
+
+def test_rng_fill(ops):
+    n = 1 << 18
+    normal, uni = torch.empty(n, device="cuda"), torch.empty(1001, device="cuda")
+    m0, m1 = torch.empty(64, 256, device="cuda"), torch.empty(64, 128, device="cuda")
+    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.rng_fill(normal, uni, m0, m1, 0.2, 1234, ctr)
+    assert int(ctr.item()) == 1
+    assert abs(normal.mean().item()) < 0.01 and abs(normal.std().item() - 1.0) < 0.01
+    assert abs((normal ** 4).mean().item() - 3.0) < 0.1                   # kurtosis of N(0,1)
+    assert 0.0 < uni.min().item() and uni.max().item() < 1.0 and abs(uni.mean().item() - 0.5) < 0.05
+    vals = torch.unique(m0).cpu()
+    assert torch.allclose(vals, torch.tensor([0.0, 1.25]))
+    assert abs((m0 > 0).float().mean().item() - 0.8) < 0.02 and abs((m1 > 0).float().mean().item() - 0.8) < 0.03
+    # same (seed, step) => same numbers; advancing the step or changing the seed => different numbers
+    a, b, c = torch.empty(4096, device="cuda"), torch.empty(4096, device="cuda"), torch.empty(4096, device="cuda")
+    c0 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.rng_fill(a, None, None, None, 0.2, 7, c0)
+    ops.rng_fill(b, None, None, None, 0.2, 7, c0)
+    c0.zero_()
+    ops.rng_fill(c, None, None, None, 0.2, 7, c0)
+    assert torch.equal(a, c) and not torch.equal(a, b)
+    assert abs(torch.corrcoef(torch.stack([a, b]))[0, 1].item()) < 0.05
