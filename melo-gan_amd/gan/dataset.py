@@ -1,0 +1,71 @@
+"""Data plane of the GAN trainer: the reference's fast-NPY contract, resident in HBM.
+
+/root/reference/src/gan/dataset.py:30-56,165-174 -- three row-aligned arrays
+<SPLITS_DIR>/<split>/{notes,emotion,numeric_features}.npy (+ optional encoder_feats.npy); an item is
+(notes float32 (T,C), emotion str|int|one-hot, latent float32 (LATENT_DIM) or zeros, numeric float32 (6)).
+Instead of 4 DataLoader worker processes restarted every epoch (train_gan.py:80) the whole split is
+uploaded once (MI355X has 288 GB; the reference split is 897 x 512 x 4 floats = 7 MB) and batches are
+device-side index_selects of a per-epoch permutation: shuffle=True, drop_last=True semantics.
+The slow per-file .npz path of the reference is out of scope.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .utils import emotion_to_index
+
+
+class GANDataset:
+    def __init__(self, notes: np.ndarray, emotions, numeric: np.ndarray, latent: Optional[np.ndarray],
+                 latent_dim: int, device="cuda"):
+        n = notes.shape[0]
+        if not (len(emotions) == n and numeric.shape[0] == n):
+            raise ValueError("NPY file length mismatch (notes, emotions, numeric_features)")
+        if latent is not None and latent.shape[0] != n:
+            print(f"[WARN] latent_feats length mismatch ({latent.shape[0]}) vs notes ({n}). Ignoring latent_feats.")
+            latent = None
+        self.n = n
+        self.notes = torch.from_numpy(np.ascontiguousarray(notes, dtype=np.float32)).to(device)
+        self.numeric = torch.from_numpy(np.ascontiguousarray(numeric, dtype=np.float32)).to(device)
+        self.latent = (torch.from_numpy(np.ascontiguousarray(latent, dtype=np.float32)) if latent is not None
+                       else torch.zeros(n, latent_dim)).to(device)
+        self.emot_idx = torch.tensor([emotion_to_index(e) for e in emotions], dtype=torch.int64, device=device)
+
+    @classmethod
+    def from_split(cls, cfg: dict, split_csv: str, latent_feats_path: Optional[str] = None, device="cuda"):
+        """prepare_dataset of the reference trainer (train_gan.py:39-60), fast-NPY path only."""
+        splits_dir = cfg.get("SPLITS_DIR", "data/splits")
+        name = Path(split_csv).stem
+        d = os.path.join(splits_dir, name)
+        paths = {k: os.path.join(d, k + ".npy") for k in ("notes", "emotion", "numeric_features")}
+        missing = [p for p in paths.values() if not os.path.exists(p)]
+        if missing:
+            raise FileNotFoundError(
+                f"fast-NPY arrays not found ({missing}); the per-file .npz path of the reference is not "
+                "implemented -- export the split to notes.npy / emotion.npy / numeric_features.npy")
+        latent = np.load(latent_feats_path) if latent_feats_path and os.path.exists(latent_feats_path) else None
+        return cls(np.load(paths["notes"]), np.load(paths["emotion"], allow_pickle=True),
+                   np.load(paths["numeric_features"]), latent, cfg["LATENT_DIM"], device)
+
+    @classmethod
+    def synthetic(cls, n: int, T: int, C: int, latent_dim: int, seed: int = 42, device="cuda"):
+        """SURVEY section 8(d) recipe: real ~ U(-1,1), numeric ~ N(0,1), latent = 0, labels uniform over 4."""
+        g = np.random.default_rng(seed)
+        return cls(g.uniform(-1, 1, (n, T, C)).astype(np.float32), g.integers(0, 4, n),
+                   g.standard_normal((n, 6)).astype(np.float32), None, latent_dim, device)
+
+    def __len__(self):
+        return self.n
+
+    def batches(self, batch_size: int, generator: Optional[torch.Generator] = None):
+        """One epoch: shuffled, drop_last (train_gan.py:80).  Yields device tensors."""
+        perm = torch.randperm(self.n, generator=generator).to(self.notes.device)
+        for i in range(self.n // batch_size):
+            idx = perm[i * batch_size:(i + 1) * batch_size]
+            yield (self.notes.index_select(0, idx), self.numeric.index_select(0, idx),
+                   self.latent.index_select(0, idx), self.emot_idx.index_select(0, idx))

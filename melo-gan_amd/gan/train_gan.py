@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""WGAN-GP trainer with numeric-feature conditioning and a frozen emotion discriminator -- the
+MI355X-native counterpart of /root/reference/src/gan/train_gan.py (same CLI, same YAML keys and
+defaults, same checkpoint layout):
+
+    python -m melo_gan_amd.gan.train_gan --config config/gan_config.yaml \
+        --ed_config config/ed_config.yaml --ed_ckpt data/models/ed/ed_best.pth
+
+Differences that do not change results: the epoch's batches come from an HBM-resident copy of the split
+(no DataLoader workers), every D-step / G-step is a replayed hipGraph over libmelogan_hip, and the three
+per-epoch scalars are accumulated on the device and read back once per epoch (the reference calls .item()
+three times per batch, train_gan.py:205,250-251).  Extra flags (--synthetic, --epochs, --no-graph) exist
+for smoke runs without the (git-ignored) dataset.
+"""
+import argparse
+import json
+import os
+import time
+
+import torch
+
+from . import config as C
+from .dataset import GANDataset
+from .engine import GanEngine
+from .utils import seed_everything
+
+
+def _scalar_writer(log_dir):
+    os.makedirs(log_dir, exist_ok=True)
+    try:                                    # same tags as the reference when tensorboard is installed
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:
+        class _Jsonl:
+            def __init__(self, d):
+                self.f = open(os.path.join(d, "scalars.jsonl"), "a")
+
+            def add_scalar(self, tag, value, step):
+                self.f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step), "wall_time": time.time()}) + "\n")
+                self.f.flush()
+
+            def close(self):
+                self.f.close()
+        return _Jsonl(log_dir)
+
+
+def load_ed_checkpoint(eng: GanEngine, path: str):
+    """train_gan.py:121-128: load_state_dict(strict=False); missing file => random ED with a warning."""
+    if not os.path.exists(path):
+        print(f"[WARN] ED checkpoint not found at {path}. ED will be random!")
+        return False
+    print(f"[INFO] Loading pre-trained Emotion Discriminator from {path}")
+    ckpt = torch.load(path, map_location="cpu")
+    sd = ckpt["model"] if "model" in ckpt else ckpt
+    for k in eng.ED.spec:
+        if k in sd and tuple(sd[k].shape) == tuple(eng.ED.spec[k]):
+            eng.ED.p[k].copy_(sd[k].float())
+    for k in eng.EDbuf:
+        if k in sd:
+            eng.EDbuf[k].copy_(sd[k].float())
+    eng._ed_folded = False
+    return True
+
+
+def save_checkpoint(eng: GanEngine, path: str, epoch=None, full=True):
+    """train_gan.py:267-282: {'epoch','G','D','E_num','opt_G','opt_D'} every SAVE_FREQ epochs; final {'G','E_num'}."""
+    sd = eng.state_dicts()
+    if not full:
+        torch.save({"G": sd["G"], "E_num": sd["E_num"]}, path)
+        return
+    opt = lambda fp, lr: {"state": {"step": float(fp.state[0].item()), "exp_avg": fp.m.cpu(), "exp_avg_sq": fp.v.cpu()},  # noqa: E731
+                          "param_groups": [{"lr": lr, "betas": eng.betas, "eps": 1e-8, "weight_decay": 0}],
+                          "layout": {k: list(v) for k, v in fp.offsets.items()}}
+    torch.save({"epoch": epoch, "G": sd["G"], "D": sd["D"], "E_num": sd["E_num"],
+                "opt_G": opt(eng.GE, eng.lr_g), "opt_D": opt(eng.D, eng.lr_d)}, path)
+
+
+def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: bool = True):
+    cfg = C.with_gan_defaults(cfg, require=not synthetic)
+    seed_everything(cfg.get("SEED", 42))
+    if not torch.cuda.is_available():
+        raise RuntimeError("melo_gan_amd has no CPU path: a MI355X (ROCm) device is required")
+    device = torch.device("cuda", torch.cuda.current_device())
+    print(f"Using main device: {device}")
+    B = cfg.get("BATCH_SIZE", 32)
+    if synthetic:
+        ds = GANDataset.synthetic(synthetic, cfg["MAX_NOTES"], cfg["NOTE_DIM"], cfg["LATENT_DIM"], cfg.get("SEED", 42), device)
+    else:
+        ds = GANDataset.from_split(cfg, cfg["TRAIN_SPLIT"], cfg.get("ENCODER_FEATS_TRAIN"), device)
+    print(f"Train set size: {len(ds)}")
+    eng = GanEngine(cfg, ed_cfg, device, B)
+    eng.init_weights(cfg.get("SEED", 42))
+    load_ed_checkpoint(eng, ed_ckpt)
+    writer = _scalar_writer(cfg.get("LOG_DIR", "experiments/gan/logs"))
+    os.makedirs(cfg.get("CHECKPOINT_DIR", "experiments/gan/checkpoints"), exist_ok=True)
+    os.makedirs(cfg.get("SAMPLE_DIR", "experiments/gan/samples"), exist_ok=True)
+    critic_iters = cfg.get("CRITIC_ITERS", 5)
+    sums = torch.zeros(3, device=device)        # sum loss_d, sum g_adv, sum g_emo (device-side accumulation)
+    shuffle_gen = torch.Generator().manual_seed(cfg.get("SEED", 42))
+    print("Starting WGAN-GP Training with Emotion Guidance...")
+    with torch.cuda.stream(eng.stream):
+        for epoch in range(1, cfg["EPOCHS"] + 1):
+            sums.zero_()
+            steps = 0
+            for batch_idx, (notes, numeric, latent, emot) in enumerate(ds.batches(B, shuffle_gen)):
+                eng.set_batch(notes, numeric, latent, emot)
+                eng.run("d_backward_rng", use_graph)
+                eng.run("d_update", use_graph)
+                sums[0:1] += eng.loss_d_out[0:1]
+                if (batch_idx + 1) % critic_iters == 0:
+                    eng.run("g_backward_rng", use_graph)
+                    eng.run("g_update", use_graph)
+                    sums[1:2] += eng.adv
+                    sums[2:3] += eng.emo
+                steps += 1
+            s = sums.tolist()                                    # the epoch's only device->host sync
+            g_steps = max(1, steps // critic_iters)
+            steps = max(1, steps)
+            print(f"Epoch {epoch}/{cfg['EPOCHS']} | D_loss: {s[0] / steps:.4f} | G_adv: {s[1] / g_steps:.4f} | "
+                  f"G_emo: {s[2] / g_steps:.4f}")
+            writer.add_scalar("Loss/Critic", s[0] / steps, epoch)
+            writer.add_scalar("Loss/Generator_Adv", s[1] / g_steps, epoch)
+            writer.add_scalar("Loss/Generator_Emo", s[2] / g_steps, epoch)
+            if epoch % cfg.get("SAVE_FREQ", 5) == 0:
+                save_checkpoint(eng, os.path.join(cfg["CHECKPOINT_DIR"], f"gan_epoch{epoch:04d}.pth"), epoch, full=True)
+    save_checkpoint(eng, os.path.join(cfg["CHECKPOINT_DIR"], "gan_final.pth"), full=False)
+    writer.close()
+    print("Training Complete.")
+    return eng
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", type=str, default="config/gan_config.yaml", help="Path to the main GAN config")
+    parser.add_argument("--ed_config", type=str, default="config/ed_config.yaml", help="Path to the ED config")
+    parser.add_argument("--ed_ckpt", type=str, default="data/models/ed/ed_best.pth")
+    parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic rolls instead of TRAIN_SPLIT")
+    parser.add_argument("--epochs", type=int, default=None, help="override EPOCHS")
+    parser.add_argument("--no-graph", action="store_true")
+    args = parser.parse_args(argv)
+    cfg = C.load_config(args.config)
+    ed_cfg = C.load_config(args.ed_config)
+    if args.epochs is not None:
+        cfg["EPOCHS"] = args.epochs
+    train(cfg, ed_cfg, args.ed_ckpt, args.synthetic, not args.no_graph)
+
+
+if __name__ == "__main__":
+    main()

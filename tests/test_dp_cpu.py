@@ -1,0 +1,86 @@
+"""N>1 path on CPU: two gloo ranks, each computing the critic/generator gradients of ITS shard with the oracle,
+averaged through melo_gan_amd's DataParallel wrapper, against a single-process emulation of the same
+semantics (shard-local BatchNorm statistics, mean of shard gradients).  No GPU involved."""
+import os
+import socket
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import melo_oracle as O
+
+B_SHARD, T, C, WORLD = 2, 16, 4, 2
+
+
+def shard_grads(rank):
+    """Flat (D, GE) gradients of one shard's D-step and G-step from identical initial parameters."""
+    cfg, ed_cfg = O.default_gan_cfg(B_SHARD, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+    real, numeric, latent, emot = O.synthetic_batch(B_SHARD, T, C, cfg["LATENT_DIM"], 6, 100 + rank)
+    R = O.step_randoms(B_SHARD, cfg["NOISE_DIM"], seed=200 + rank)
+    dcopy = {k: v.clone() for k, v in S.PD.items()}
+    rd = O.d_step(S, real, latent, numeric, R["noise_d"], R["alpha"], R["dm_d"])
+    for k in S.PD:                                   # undo the local Adam step: replicas update after the all-reduce
+        S.PD[k].copy_(dcopy[k])
+    rg = O.g_step(S, latent, numeric, emot, R["noise_g"], R["dm_g"])
+    fd = torch.cat([rd["grads"][k].flatten() for k in S.PD])
+    fg = torch.cat([rg["grads"][k].flatten() for k in rg["grads"]])
+    return fd, fg
+
+
+def _worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.gan.dp import DataParallel
+    torch.set_num_threads(1)
+    fd, fg = shard_grads(rank)
+    params = torch.full((8,), float(rank))
+    eng = types.SimpleNamespace(D=types.SimpleNamespace(grad=fd.clone(), data=params.clone()),
+                                GE=types.SimpleNamespace(grad=fg.clone(), data=params.clone() + 1), world_size=1)
+    dp = DataParallel(eng, WORLD, dist)
+    dp.broadcast_params()
+    assert eng.world_size == WORLD
+    assert torch.equal(eng.D.data, torch.zeros(8)) and torch.equal(eng.GE.data, torch.ones(8))   # rank 0's values
+    dp.allreduce_d()
+    dp.allreduce_g()
+    if rank == 0:
+        torch.save({"d": eng.D.grad / WORLD, "g": eng.GE.grad / WORLD}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_average_matches_emulation(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "avg.pt")
+    mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
+    got = torch.load(out)
+    torch.set_num_threads(1)
+    ds, gs = zip(*[shard_grads(r) for r in range(WORLD)])
+    torch.testing.assert_close(got["d"], sum(ds) / WORLD, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(got["g"], sum(gs) / WORLD, rtol=1e-6, atol=1e-9)
+
+
+def test_critic_gradient_is_shardable():
+    """Every critic loss term is a mean of per-sample terms: with the SAME fake batch, the mean
+    of two half-batch gradients equals the full-batch gradient (the critic has no BatchNorm)."""
+    cfg, ed_cfg = O.default_gan_cfg(4, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+    real, numeric, _, _ = O.synthetic_batch(4, T, C, cfg["LATENT_DIM"], 6, 5)
+    fake = O.closed_form((4, T, C), 3.3, 0.5)
+    alpha = torch.rand(4, 1, 1, generator=torch.Generator().manual_seed(1))
+    emb = O.feature_encoder_fwd(S.PE, numeric, None).detach()
+
+    def grads(sl):
+        P = {k: v.clone().requires_grad_(True) for k, v in S.PD.items()}
+        loss = (O.discriminator_fwd(P, fake[sl], emb[sl]).mean() - O.discriminator_fwd(P, real[sl], emb[sl]).mean()
+                + 10.0 * O.gradient_penalty(P, real[sl], fake[sl], emb[sl], alpha[sl]))
+        return torch.autograd.grad(loss, list(P.values()))
+    full, a, b = grads(slice(0, 4)), grads(slice(0, 2)), grads(slice(2, 4))
+    for f, x, y in zip(full, a, b):
+        torch.testing.assert_close((x + y) / 2, f, rtol=1e-4, atol=1e-7)
