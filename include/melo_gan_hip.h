@@ -224,6 +224,9 @@ size_t mg_grad_norm_workspace_bytes(long n);
 /* ---- VAE extras (src/ae/model.py:127-133, src/ae/train_ae.py:35-51) ---- */
 /* z = mu + eps*exp(0.5*logvar) */
 int mg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long n, mg_stream_t stream);
+/* backward of the reparameterisation: dmu = dz + dmu_kld ; dlv = dz*eps*0.5*exp(0.5*logvar) + dlv_kld */
+int mg_reparam_bwd(const float* dz, const float* logvar, const float* eps, const float* dmu_kld,
+                   const float* dlv_kld, float* dmu, float* dlv, long n, mg_stream_t stream);
 /* mse = mean((recon-x)^2); kld = -0.5*mean(1+lv-mu^2-exp(lv)); out = {total, mse, kld};
  * drecon = 2(recon-x)/n_x ; dmu, dlv include beta-weighted KLD grads PLUS the z-path grads are added by caller */
 int mg_vae_loss(const float* recon, const float* x, long n_x, const float* mu, const float* logvar, long n_z,

@@ -573,6 +573,14 @@ __global__ void reparam_kernel(const float* mu, const float* lv, const float* ep
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) z[i] = mu[i] + eps[i] * expf(0.5f * lv[i]);
 }
+// dmu = dz + dmu_kld ; dlv = dz*eps*0.5*exp(0.5*lv) + dlv_kld      (backward of z = mu + eps*exp(0.5*lv))
+__global__ void reparam_bwd_kernel(const float* dz, const float* lv, const float* eps, const float* dmu_kld,
+                                   const float* dlv_kld, float* dmu, float* dlv, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dmu[i] = dz[i] + (dmu_kld ? dmu_kld[i] : 0.f);
+    dlv[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * lv[i]) + (dlv_kld ? dlv_kld[i] : 0.f);
+}
 __global__ __launch_bounds__(1024) void vae_loss_kernel(const float* __restrict__ recon, const float* __restrict__ x,
                                                         long n_x, const float* __restrict__ mu,
                                                         const float* __restrict__ lv, long n_z, float beta,
@@ -874,6 +882,14 @@ int mg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float
     MG_CHECK_ARG(mu && logvar && eps && z && n > 0, "mg_reparam_fwd: bad args");
     hipLaunchKernelGGL(reparam_kernel, dim3(nblk(n)), dim3(256), 0, ST, mu, logvar, eps, z, n);
     MG_CHECK_LAUNCH("reparam");
+    return MG_OK;
+}
+
+int mg_reparam_bwd(const float* dz, const float* logvar, const float* eps, const float* dmu_kld,
+                   const float* dlv_kld, float* dmu, float* dlv, long n, mg_stream_t stream) {
+    MG_CHECK_ARG(dz && logvar && eps && dmu && dlv && n > 0, "mg_reparam_bwd: bad args");
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(nblk(n)), dim3(256), 0, ST, dz, logvar, eps, dmu_kld, dlv_kld, dmu, dlv, n);
+    MG_CHECK_LAUNCH("reparam_bwd");
     return MG_OK;
 }
 

@@ -596,6 +596,13 @@ def reparam_fwd(mu, logvar, eps, z):
     L.check(L.load().mg_reparam_fwd(_p(mu), _p(logvar), _p(eps), _p(z), mu.numel(), _stream()), "mg_reparam_fwd")
 
 
+def reparam_bwd(dz, logvar, eps, dmu_kld, dlv_kld, dmu, dlv):
+    for t in (dz, logvar, eps, dmu_kld, dlv_kld, dmu, dlv):
+        _chk(t, "t", dz.shape)
+    L.check(L.load().mg_reparam_bwd(_p(dz), _p(logvar), _p(eps), _p(dmu_kld), _p(dlv_kld), _p(dmu), _p(dlv),
+                                    dz.numel(), _stream()), "mg_reparam_bwd")
+
+
 def vae_loss(recon, x, mu, logvar, beta, out, drecon=None, dmu=None, dlv=None):
     _chk(recon, "recon")
     _chk(x, "x", recon.shape)
