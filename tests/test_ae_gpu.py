@@ -72,3 +72,20 @@ def test_vae_steps_match_reference():
             if upd_ref.norm() > 0 and k not in PRE_BN_BIAS:
                 assert rel_err(upd, upd_ref) < 0.15, (it, k, rel_err(upd, upd_ref))
         eng.load_state(P, Bf)
+
+
+def test_ae_trainer_cli_smoke(tmp_path):
+    import yaml
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.ae import train_ae
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "config", "ae_config.yaml")))
+    cfg.update(MAX_NOTES=32, BATCH_SIZE=8, EPOCHS=2, CHECKPOINT_DIR=str(tmp_path / "ck"), LOG_DIR=str(tmp_path / "log"))
+    p = tmp_path / "ae.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    train_ae.main(["--config", str(p), "--synthetic", "32"])
+    best = torch.load(tmp_path / "ck" / "ae_best.pth", map_location="cpu")
+    final = torch.load(tmp_path / "ck" / "ae_final.pth", map_location="cpu")
+    assert set(best) == {"epoch", "model_state"} and set(best["model_state"]) == set(final)
+    spec, bufs = O.vae_spec(32, 8)
+    assert set(spec) | set(bufs) <= set(final) and "encoder._linear.1.weight" in final
+    assert all(torch.isfinite(v.float()).all() for v in final.values())
