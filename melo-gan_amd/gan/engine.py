@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import math
 from collections import OrderedDict
+from contextlib import contextmanager
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -261,6 +262,9 @@ class GanEngine:
         self._graphs = {}
         # hipGraph capture is illegal on the null stream: every step runs on this side stream
         self.stream = torch.cuda.Stream(device=d)
+        # side streams: independent branches of a step (weight gradients next to the data-gradient chain, the
+        # critic next to the emotion discriminator) run concurrently and are captured as parallel graph branches
+        self.side = [torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)]
         self.world_size = 1
         self._ed_folded = False
 
@@ -461,6 +465,20 @@ class GanEngine:
                              gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1])
         ops.conv1d_dgrad(self.ed_dz[0], P["encoder.conv.0.net.0.weight"], dnotes, 1)
 
+    @contextmanager
+    def _branch(self, i: int):
+        """Run the enclosed launches on side stream i, ordered after everything enqueued so far on the
+        current stream (fork).  _join() makes the current stream wait for the side streams again."""
+        s = self.side[i]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            yield
+
+    def _join(self):
+        cur = torch.cuda.current_stream()
+        for s in self.side:
+            cur.wait_stream(s)
+
     # -------------------------------------------------------------------------------------
     # D-step  (src/gan/train_gan.py:183-205)
     # -------------------------------------------------------------------------------------
@@ -476,23 +494,27 @@ class GanEngine:
         self._d_bwd_input(self.ds_d, 3 * B, None)
         ops.conv1d_dgrad(self.dZ1[2 * B:], P["conv.0.weight"], self.gx, 2)
         ops.gp_penalty(self.gx, self.TAN0, self.norms, self.gp, self.lambda_gp)
-        # tangent pass: d(lambda*gp)/d(grad_xhat) pushed forward through the masked linear critic
+        # Weight gradients are [real,fake] activations x Wasserstein dZ + tangent activations x penalty dZ; each
+        # becomes launchable as soon as its tangent exists, so they run on side streams next to the tangent pass
+        # (d(lambda*gp)/d(grad_xhat) pushed forward through the masked linear critic).
+        with self._branch(0):
+            ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:])
+            ops.colsum(self.dZ1[:2 * B], G["conv.0.bias"])
+            ops.colsum(self.dZ2[:2 * B], G["conv.2.bias"])
+            ops.colsum(self.dZ3[:2 * B], G["conv.4.bias"])
+            ops.colsum(self.dU[:2 * B], G["fc.1.bias"])
         ops.conv1d_fwd(self.TAN0, P["conv.0.weight"], self.TAN1, 2, gref=self.A1[2 * B:], gact=ACT_LRELU)
+        with self._branch(1):
+            ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:])
         ops.conv1d_fwd(self.TAN1, P["conv.2.weight"], self.TAN2, 2, gref=self.A2[2 * B:], gact=ACT_LRELU)
         ops.conv1d_fwd(self.TAN2, P["conv.4.weight"], self.TZ3, 2, gref=self.A3[2 * B:], gact=ACT_LRELU)
+        ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:])
         ops.meanT_fwd(self.TZ3, self.ghb)
         ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[2 * B:], gact=ACT_LRELU)
-        # weight gradients: [real,fake] activations x Wasserstein dZ  +  tangent activations x penalty dZ
-        ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:])
-        ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:])
-        ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:])
         ops.linear_wgrad(self.H[:2 * B], self.dU[:2 * B], G["fc.1.weight"], self.ghb, self.dU[2 * B:])
-        ops.colsum(self.dZ1[:2 * B], G["conv.0.bias"])
-        ops.colsum(self.dZ2[:2 * B], G["conv.2.bias"])
-        ops.colsum(self.dZ3[:2 * B], G["conv.4.bias"])
-        ops.colsum(self.dU[:2 * B], G["fc.1.bias"])
         ops.dhead_wgrad(self.ds_d, self.Fh, self.emb, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"], 2 * B, B)
         ops.wgan_d_loss(self.s, self.gp, self.lambda_gp, self.loss_d_out, B)
+        self._join()
 
     def d_backward_rng(self):
         """Production D-step front half: device RNG draw + d_backward as one capturable sequence."""
@@ -518,66 +540,79 @@ class GanEngine:
             self.fold_ed()
         self._e_fwd(train=True)
         self._g_fwd(self.notes, train=True)
-        self._d_fwd(self.notes, B)
-        ops.neg_mean(self.s[:B], self.adv)
+        # the critic branch (forward + input gradient) runs beside the emotion-discriminator branch
+        with self._branch(0):
+            self._d_fwd(self.notes, B)
+            ops.neg_mean(self.s[:B], self.adv)
+            self._d_bwd_input(self.ds_g, B, self.demb)
         self._ed_fwd(self.notes)
         ops.softmax_ce(self.logits, self.emot_idx, self.emo, self.dlogits, self.lambda_emo)
-        # ---- input gradients of the two critics ----
         if self.ed_mode == "notes":
             self._ed_bwd(self.dnotes)
             acc = True
         else:
             self._ed_bwd(None)
             acc = False
-        self._d_bwd_input(self.ds_g, B, self.demb)
+        self._join()
         ops.conv1d_dgrad(self.dZ1[:B], self.D.p["conv.0.weight"], self.dnotes, 2, accumulate=acc)
-        # ---- generator backward ----
+        # ---- generator backward: data-gradient chain on this stream, weight/bias gradients on side streams ----
         dn = self.dnotes
         if self.dn_dense is not None:      # zero-padded tail rows carry no gradient (models.py:78-81)
             ops.copy_cols(self.dnotes.view(B, -1), 0, self.dn_dense.view(B, -1), 0, self.L3 * self.C)
             dn = self.dn_dense
-        ops.colsum(dn, GG("decoder.deconv.6.bias"))
-        ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"))
+        with self._branch(0):
+            ops.colsum(dn, GG("decoder.deconv.6.bias"))
+            ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"))
         ops.convT1d_dgrad(dn, PG("decoder.deconv.6.weight"), self.d_ad3)
         ops.bn_train_bwd(self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, PG("decoder.deconv.4.weight"), self.bn_mean[1],
                          self.bn_invstd[1], GG("decoder.deconv.4.weight"), GG("decoder.deconv.4.bias"), ACT_RELU)
-        ops.colsum(self.d_zd3, GG("decoder.deconv.3.bias"))
-        ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"))
+        with self._branch(1):
+            ops.colsum(self.d_zd3, GG("decoder.deconv.3.bias"))
+            ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"))
         ops.convT1d_dgrad(self.d_zd3, PG("decoder.deconv.3.weight"), self.d_ad0)
         ops.bn_train_bwd(self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, PG("decoder.deconv.1.weight"), self.bn_mean[0],
                          self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
-        ops.colsum(self.d_zd0, GG("decoder.deconv.0.bias"))
-        ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"))
+        with self._branch(0):
+            ops.colsum(self.d_zd0, GG("decoder.deconv.0.bias"))
+            ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"))
         ops.convT1d_dgrad(self.d_zd0, PG("decoder.deconv.0.weight"), self.d_y0)
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
         ops.act_bwd(self.d_p2, self.d_p2, gref=self.a_p2, gact=ACT_RELU)
-        ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"))
-        ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
+        with self._branch(1):
+            ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"))
+            ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
-        ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"))
-        ops.colsum(self.d_p0, GG("decoder.pre.0.bias"))
+        with self._branch(0):
+            ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"))
+            ops.colsum(self.d_p0, GG("decoder.pre.0.bias"))
         ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
         if self.ed_mode != "notes":
             ops.axpby(self.ed_dfeat, self.d_lat, 1.0, 1.0)
-        ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"))
-        ops.colsum(self.d_lat, GG("noise_to_latent.net.2.bias"))
+        with self._branch(1):
+            ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"))
+            ops.colsum(self.d_lat, GG("noise_to_latent.net.2.bias"))
         ops.linear_dgrad(self.d_lat, PG("noise_to_latent.net.2.weight"), self.d_n0, gref=self.a_n0, gact=ACT_RELU)
-        ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"))
-        ops.colsum(self.d_n0, GG("noise_to_latent.net.0.bias"))
+        with self._branch(0):
+            ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"))
+            ops.colsum(self.d_n0, GG("noise_to_latent.net.0.bias"))
         ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
         # embedding gradient = generator-input slice + critic-head path, then E_num backward
         ops.copy_cols(self.d_gin, self.noise_dim, self.demb, 0, self.E, accumulate=True)
-        ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"))
-        ops.colsum(self.demb, GEg("net.7.bias"))
+        with self._branch(1):
+            ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"))
+            ops.colsum(self.demb, GEg("net.7.bias"))
         ops.linear_dgrad(self.demb, PE("net.7.weight"), self.d_ez2, gref=self.e_z2, gact=ACT_GELU, emul=self.dmask[1])
-        ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"))
-        ops.colsum(self.d_ez2, GEg("net.4.bias"))
+        with self._branch(0):
+            ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"))
+            ops.colsum(self.d_ez2, GEg("net.4.bias"))
         ops.linear_dgrad(self.d_ez2, PE("net.4.weight"), self.d_ez1, gref=self.e_z1, gact=ACT_GELU, emul=self.dmask[0])
-        ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"))
-        ops.colsum(self.d_ez1, GEg("net.1.bias"))
+        with self._branch(1):
+            ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"))
+            ops.colsum(self.d_ez1, GEg("net.1.bias"))
         ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
         ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
+        self._join()
 
     def g_update(self):
         ops.adam_flat(self.GE.data, self.GE.grad, self.GE.m, self.GE.v, self.GE.state, self.lr_g, *self.betas,

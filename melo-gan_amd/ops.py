@@ -233,9 +233,10 @@ _ws_cache = {}
 
 
 def workspace(nbytes: int, device, tag: str = "default") -> Tensor:
-    """Grow-only scratch buffer per (device, tag).  Allocation happens outside graph capture
-    because every engine warms up eagerly before capturing."""
-    key = (str(device), tag)
+    """Grow-only scratch buffer per (device, tag, current stream) -- launches that may run concurrently on
+    different streams never share scratch.  Allocation happens outside graph capture because every engine
+    warms up eagerly (same stream assignment) before capturing."""
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
