@@ -71,11 +71,15 @@ const char* mg_last_error(void);
  *             Conv1d stride-1 data-gradient (flip=1; w_sn=K, w_sc=Cin*K);
  *             Linear data-gradient (K=1; w_sn=1, w_sc=in).
  *   x batch stride xbs, y batch stride ybs (elements; 0 => dense).
+ *   work/work_bytes: optional scratch (mg_conv_workspace_bytes(B, Tout, N)); when given and the output
+ *   tiling alone would leave most CUs idle, the channel reduction is split over workgroups into partial
+ *   slabs that a second kernel sums in fixed order before the epilogue.  NULL => never split.
  */
+size_t mg_conv_workspace_bytes(int B, int Tout, int N);
 int mg_conv1d_gather(const float* x, const float* w, float* y,
                      int B, int Tin, int Cin, int N, int K, int stride, int flip,
                      int w_sn, int w_sc, long xbs, long ybs,
-                     const mg_epilogue* epi, mg_stream_t stream);
+                     const mg_epilogue* epi, void* work, size_t work_bytes, mg_stream_t stream);
 
 /* mg_conv1d_scatter2: stride-2, K=5, padding 2, output_padding 1 transposed convolution
  *   y[b,t,n] = EPI( sum_{k,c : t+2-k even} x[b,(t+2-k)/2,c] * W(n,c,k) ),  t < Tout,
@@ -88,7 +92,7 @@ int mg_conv1d_gather(const float* x, const float* w, float* y,
 int mg_conv1d_scatter2(const float* x, const float* w, float* y,
                        int B, int Tin, int Cin, int N, int Tout,
                        int w_sn, int w_sc, long xbs, long ybs,
-                       const mg_epilogue* epi, mg_stream_t stream);
+                       const mg_epilogue* epi, void* work, size_t work_bytes, mg_stream_t stream);
 
 /* ---- skinny GEMM for nn.Linear forward / data-gradient with few rows (M = batch) ----
  *   y[M,N] = EPI( x[M,K] @ W^T ),  W(n,c) = w[n*w_sn + c*w_sc], one of the strides must be 1:

@@ -20,8 +20,9 @@ class Epilogue(C.Structure):
 SIGNATURES = {
     "mg_version": (i32, []),
     "mg_last_error": (C.c_char_p, []),
-    "mg_conv1d_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
-    "mg_conv1d_scatter2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
+    "mg_conv_workspace_bytes": (sz, [i32, i32, i32]),
+    "mg_conv1d_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, sz, vp]),
+    "mg_conv1d_scatter2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_linear_workspace_bytes": (sz, [i32, i32, i32]),
     "mg_linear": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_conv_tile_config": (i32, [i64, i32, i32]),

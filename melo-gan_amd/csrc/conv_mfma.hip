@@ -33,6 +33,11 @@ struct ConvP {
     int flip;
     int tt_log2;
     int n_ttiles;
+    int ksplit;       // channel-chunk ranges handled by different workgroups (blockIdx.z); 1 => none
+    int cps;          // chunks per split
+    float* part;      // [ksplit][B*Tout*N] raw partial sums when ksplit > 1
+    void* work;       // caller workspace (may be null)
+    size_t work_bytes;
     mg_epilogue e;
 };
 
@@ -98,6 +103,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                 for (int r = 0; r < 16; ++r) acc[ph][mi][ni][r] = 0.f;
 
     const bool vec_ok = ((p.Cin & 3) == 0) && ((p.xbs & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
+    // split-K: this workgroup reduces over channels [c_begin, c_end) only
+    const int c_begin = blockIdx.z * p.cps * BKC;
+    const int c_end = min(p.Cin, c_begin + p.cps * BKC);
     const bool w_nck = p.w_sc < p.w_sn;   // (c,k) contiguous for a fixed n
 
     // one chunk of MFMAs out of LDS
@@ -251,12 +259,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         };
         // double-buffered LDS: chunk i+1 is written to the other buffer right after chunk i's MFMAs,
         // one barrier per chunk
-        load_chunk(0);
+        load_chunk(c_begin);
         store_chunk(0);
         __syncthreads();
         int cur = 0;
-        for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
-            const bool more = c0 + BKC < p.Cin;
+        for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
+            const bool more = c0 + BKC < c_end;
             if (more) load_chunk(c0 + BKC);
             compute(BKC / 2, cur);
             if (more) store_chunk(buf_floats - cur);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             cur = buf_floats - cur;
         }
     } else {
-    for (int c0 = 0; c0 < p.Cin; c0 += BKC) {
+    for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
         __syncthreads();
         // ---- stage the input window chunk: rows (seg, r) x BKC channels ----
         if (vec_ok) {
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             }
         }
         __syncthreads();
-        const int crem = p.Cin - c0;
+        const int crem = c_end - c0;
         compute((crem >= BKC ? BKC : crem + 1) >> 1, 0);
     }
     }
@@ -337,6 +345,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                     if (TR2 && tout >= p.Tout) continue;
                     const long di = ((long)b * p.Tout + tout) * p.N + n;
                     const long yi = (long)b * p.ybs + (long)tout * p.N + n;
+                    if (p.ksplit > 1) {      // raw partial sum; conv_finish_kernel adds the slabs and runs the epilogue
+                        p.part[(long)blockIdx.z * ((long)p.B * p.Tout * p.N) + di] = acc[ph][mi][ni][r];
+                        continue;
+                    }
                     float v = acc[ph][mi][ni][r] + bias;
                     v = v * scale + shift;
                     if (E.zout) E.zout[di] = v;
@@ -350,6 +362,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             }
         }
     }
+}
+
+// sums the split-K slabs in fixed order and applies the fused epilogue
+__global__ void conv_finish_kernel(const float* __restrict__ part, float* __restrict__ y, long total, int Tout, int N,
+                                   long ybs, int ksplit, const mg_epilogue e) {
+    const long di = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (di >= total) return;
+    float v = 0.f;
+    for (int z = 0; z < ksplit; ++z) v += part[(long)z * total + di];
+    const int n = (int)(di % N);
+    v = mg_apply_epilogue(e, v, n, di);
+    const long bt = di / N;
+    const long yi = (bt / Tout) * ybs + (bt % Tout) * N + n;
+    if (e.accumulate) v += y[yi];
+    y[yi] = v;
 }
 
 template <int S, int K, bool TR2, int TM, int TN>
@@ -382,8 +409,30 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid((unsigned)(p.n_ttiles * mg_cdiv(p.B, TB)), (unsigned)mg_cdiv(p.N, BN));
+    // split-K over workgroups when the output tiling alone leaves most of the 256 CUs idle
+    const int nchunks = (int)mg_cdiv(p.Cin, BKC);
+    const long n_wgs = (long)grid.x * grid.y;
+    const long total = (long)p.B * p.Tout * p.N;
+    p.ksplit = 1;
+    p.cps = nchunks;
+    if (p.work && n_wgs < 192 && nchunks >= 4) {
+        int ks = 1;
+        while (ks < 8 && n_wgs * ks < 256 && nchunks / (ks * 2) >= 2) ks *= 2;
+        if (ks > 1 && p.work_bytes >= (size_t)ks * total * sizeof(float)) {
+            p.ksplit = ks;
+            p.cps = (int)mg_cdiv(nchunks, ks);
+            p.ksplit = (int)mg_cdiv(nchunks, p.cps);
+            p.part = (float*)p.work;
+            grid.z = (unsigned)p.ksplit;
+        }
+    }
     hipLaunchKernelGGL((conv_wgemm_kernel<S, K, TR2, TM, TN>), grid, dim3(256), lds, stream, p);
     MG_CHECK_LAUNCH("conv_wgemm");
+    if (p.ksplit > 1) {
+        hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)mg_cdiv(total, 256)), dim3(256), 0, stream,
+                           (const float*)p.part, p.y, total, p.Tout, p.N, p.ybs, p.ksplit, p.e);
+        MG_CHECK_LAUNCH("conv_finish");
+    }
     return MG_OK;
 }
 
@@ -428,7 +477,7 @@ int fill_epilogue(ConvP& p, const mg_epilogue* epi) {
 
 extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B, int Tin, int Cin, int N, int K,
                                 int stride, int flip, int w_sn, int w_sc, long xbs, long ybs,
-                                const mg_epilogue* epi, mg_stream_t stream) {
+                                const mg_epilogue* epi, void* work, size_t work_bytes, mg_stream_t stream) {
     MG_CHECK_ARG(x && w && y, "mg_conv1d_gather: null tensor");
     MG_CHECK_ARG(B > 0 && Tin > 0 && Cin > 0 && N > 0, "mg_conv1d_gather: bad shape B=%d Tin=%d Cin=%d N=%d", B, Tin, Cin, N);
     MG_CHECK_ARG(K == 1 || K == 3 || K == 5, "mg_conv1d_gather: K=%d unsupported", K);
@@ -444,6 +493,7 @@ extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B,
     p.xbs = xbs ? xbs : (long)Tin * Cin;
     p.ybs = ybs ? ybs : (long)Tout * N;
     p.w_sn = w_sn; p.w_sc = w_sc; p.flip = flip;
+    p.work = work; p.work_bytes = work_bytes;
     { const long xb = ((long)(B - 1) * p.xbs + (long)Tin * Cin) * 4; p.x_bytes = xb < (1L << 31) ? xb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -459,7 +509,7 @@ extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B,
 
 extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int B, int Tin, int Cin, int N,
                                   int Tout, int w_sn, int w_sc, long xbs, long ybs, const mg_epilogue* epi,
-                                  mg_stream_t stream) {
+                                  void* work, size_t work_bytes, mg_stream_t stream) {
     MG_CHECK_ARG(x && w && y, "mg_conv1d_scatter2: null tensor");
     MG_CHECK_ARG(B > 0 && Tin > 0 && Cin > 0 && N > 0, "mg_conv1d_scatter2: bad shape");
     MG_CHECK_ARG(Tout == 2 * Tin || Tout == 2 * Tin - 1, "mg_conv1d_scatter2: Tout=%d must be 2*Tin or 2*Tin-1", Tout);
@@ -469,6 +519,7 @@ extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int 
     p.xbs = xbs ? xbs : (long)Tin * Cin;
     p.ybs = ybs ? ybs : (long)p.Tout * N;
     p.w_sn = w_sn; p.w_sc = w_sc; p.flip = 0;
+    p.work = work; p.work_bytes = work_bytes;
     { const long xb = ((long)(B - 1) * p.xbs + (long)Tin * Cin) * 4; p.x_bytes = xb < (1L << 31) ? xb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -478,6 +529,9 @@ extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int 
 
 // Which template instantiation a call would launch: returns TM*10+TN of conv_wgemm_kernel<S,K,TR2,TM,TN>
 // (22 = 128x128 tile, 11 = 64x64, 12 = 64x128 two-phase).  m_rows = B*Tout (gather) or B*Tin (scatter2).
+// workspace that lets the window GEMMs split the channel reduction over workgroups (<= 8 output-sized slabs)
+extern "C" size_t mg_conv_workspace_bytes(int B, int Tout, int N) { return (size_t)8 * B * Tout * N * sizeof(float); }
+
 extern "C" int mg_conv_tile_config(long m_rows, int N, int scatter2) {
     return scatter2 ? scatter_tile(m_rows, N) : gather_tile(m_rows, N);
 }

@@ -88,6 +88,13 @@ def _numel(shape):
 # ---------------------------------------------------------------------------------------
 # window GEMMs
 # ---------------------------------------------------------------------------------------
+def _conv_work(lib, B, Tout, N, Cin, device):
+    """Split-K scratch for small-output convolutions (only they can use it: <= 8 MB of output)."""
+    if Cin < 64 or B * Tout * N > (1 << 21):
+        return None
+    return workspace(lib.mg_conv_workspace_bytes(B, Tout, N), device, "conv")
+
+
 def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_sn: int, w_sc: int,
                 flip: bool = False, y_rows: Optional[int] = None, **epi) -> Tensor:
     """Generic gather window-GEMM (see mg_conv1d_gather).  x: (B, Tin, Cin); y: (B, Ty, N) with
@@ -111,9 +118,11 @@ def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_
     lib = L.load()
     sym = lambda: "conv_wgemm_kernel<%d,%d,false,%s>" % (  # noqa: E731
         stride, K, {22: "2,2", 12: "1,2", 11: "1,1"}[lib.mg_conv_tile_config(B * Tout, N, 0)])
+    work = _conv_work(lib, B, Tout, N, Cin, x.device)
     with _observe(sym, 2.0 * B * Tout * N * Cin * K):
         rc = lib.mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
-                                  Tin * Cin, y.shape[1] * N, C.byref(e), _stream())
+                                  Tin * Cin, y.shape[1] * N, C.byref(e), _p(work), work.numel() if work is not None else 0,
+                                  _stream())
     L.check(rc, "mg_conv1d_gather")
     return y
 
@@ -136,9 +145,10 @@ def conv_scatter2(x: Tensor, w: Tensor, y: Tensor, N: int, w_sn: int, w_sc: int,
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
     lib = L.load()
     sym = lambda: f"conv_wgemm_kernel<2,5,true,{'1,2' if lib.mg_conv_tile_config(B * Tin, N, 1) == 12 else '1,1'}>"  # noqa: E731
+    work = _conv_work(lib, B, Tout, N, Cin, x.device)
     with _observe(sym, 2.0 * B * Tin * N * Cin * 5):
         rc = lib.mg_conv1d_scatter2(_p(x), _p(w), _p(y), B, Tin, Cin, N, Tout, w_sn, w_sc, Tin * Cin, y.shape[1] * N,
-                                    C.byref(e), _stream())
+                                    C.byref(e), _p(work), work.numel() if work is not None else 0, _stream())
     L.check(rc, "mg_conv1d_scatter2")
     return y
 
