@@ -11,8 +11,8 @@ synthetic (B, T=256, C=128) rolls resident in HBM, including the per-step device
 the gradient all-reduce (N>1) and both Adam updates.  value = N*B*K / max-over-ranks wall time.
 
 The same JSON line carries
-  roofline     : the dominant kernel SYMBOL (stride-1 K=3 64x128-tile window-GEMM: ED conv2/conv3 forward
-                 and conv3 data-gradient, 16.1 of the step's 56.9 GFLOP), algorithmic FLOPs / HIP-event
+  roofline     : the dominant kernel SYMBOL (stride-1 K=3 64x64-tile window-GEMM: ED conv1-3 forward and their
+                 data-gradients, 6 launches = 20.9 of the step's 56.9 GFLOP), algorithmic FLOPs / HIP-event
                  time of exactly those launches, against the dense fp32-MFMA peak (157.3 TFLOP/s);
   cpu_baseline : the oracle (PyTorch-CPU fp32 restatement of the reference step) timed on this
                  host's cores on a bounded number of the same steps (rank 0, N=1 only).
@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 B_PER_GPU, T, C = 64, 256, 128
-DOMINANT = "conv_wgemm_kernel<1,3,false,1,2>"
+DOMINANT = "conv_wgemm_kernel<1,3,false,1,1>"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
 # conv+linear FLOPs per sample of one (1D+1G) step at cfg2 as the reference executes it
 MFLOP_PER_SAMPLE = 889.6

@@ -17,6 +17,7 @@
 // fp32 MFMA issues one 32x32x2 every 64 cycles per SIMD, i.e. the matrix pipe -- not LDS or
 // HBM -- bounds this kernel by a wide margin: 2 A + 2 B ds_read_b32 feed 4 MFMAs (256 cycles).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct ConvP {
     int flip;
     int tt_log2;
     int n_ttiles;
+    int dbuf;         // 1: two LDS buffers, one barrier per chunk; 0: one buffer, two barriers (more WGs per CU)
     int ksplit;       // channel-chunk ranges handled by different workgroups (blockIdx.z); 1 => none
     int cps;          // chunks per split
     float* part;      // [ksplit][B*Tout*N] raw partial sums when ksplit > 1
@@ -263,13 +265,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         store_chunk(0);
         __syncthreads();
         int cur = 0;
-        for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
-            const bool more = c0 + BKC < c_end;
-            if (more) load_chunk(c0 + BKC);
-            compute(BKC / 2, cur);
-            if (more) store_chunk(buf_floats - cur);
-            __syncthreads();
-            cur = buf_floats - cur;
+        if (p.dbuf) {
+            for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
+                const bool more = c0 + BKC < c_end;
+                if (more) load_chunk(c0 + BKC);
+                compute(BKC / 2, cur);
+                if (more) store_chunk(buf_floats - cur);
+                __syncthreads();
+                cur = buf_floats - cur;
+            }
+        } else {
+            for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
+                const bool more = c0 + BKC < c_end;
+                if (more) load_chunk(c0 + BKC);
+                compute(BKC / 2, 0);
+                __syncthreads();
+                if (more) {
+                    store_chunk(0);
+                    __syncthreads();
+                }
+            }
         }
     } else {
     for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
@@ -393,7 +408,12 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     const int TT = 1 << lg, TB = BM >> lg;
     p.n_ttiles = (int)mg_cdiv(p.Tm, TT);
     const int R = (TT - 1) * SA + NR;
-    const size_t lds = 2 * ((size_t)((TB * R * SX + 3) & ~3) + (size_t)BKC * K * SW) * sizeof(float);
+    const size_t lds1 = ((size_t)((TB * R * SX + 3) & ~3) + (size_t)BKC * K * SW) * sizeof(float);
+    // single LDS buffer by default: twice the resident workgroups beat saving one barrier per chunk in every
+    // shape measured (e.g. 94.9 vs 85.6 TFLOP/s on the ED conv3 shape); MG_FORCE_DBUF=1 re-enables the double buffer
+    p.dbuf = 0;
+    if (const char* f = getenv("MG_FORCE_DBUF")) p.dbuf = atoi(f) ? 1 : 0;
+    const size_t lds = (p.dbuf ? 2 : 1) * lds1;
     if (lds > 160 * 1024) {
         mg_set_error("conv_wgemm: LDS request %zu too large", lds);
         return MG_EUNSUP;
@@ -436,18 +456,23 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     return MG_OK;
 }
 
-// Tile choice.  The fp32 matrix pipe needs >= 2 waves per SIMD to cover LDS/barrier bubbles (measured: the
-// 128x128 tile at 1 workgroup/CU reaches 68 TFLOP/s, at >= 2/CU 93-100), so a tile is only taken if it still
-// yields ~2 workgroups per CU; otherwise the next smaller one.  Returns TM*10+TN.
+// Tile choice.  Measured on MI355X (scratch microbenchmarks, ED conv3 shape and the critic's stride-2 layers):
+// the fp32 matrix pipe is fed best by MANY waves per SIMD, not by big register tiles -- 64x64 tiles with a single
+// LDS buffer (4-5 workgroups per CU) reach 95-107 TFLOP/s where 128x128 (1 workgroup/CU) reaches 68 and
+// 64x128 75-90.  So 64x64 is the default; the wider instantiations stay selectable (MG_FORCE_TILE=22|12) for
+// tuning on other shapes.  Returns TM*10+TN.
 int gather_tile(long m_total, int N) {
-    if (N > 64) {
-        if (mg_cdiv(m_total, 128) * mg_cdiv(N, 128) >= 512) return 22;
-        if (mg_cdiv(m_total, 64) * mg_cdiv(N, 128) >= 384) return 12;
+    if (const char* f = getenv("MG_FORCE_TILE")) {
+        const int t = atoi(f);
+        if ((t == 22 || t == 12) && N > 64) return t;
     }
+    (void)m_total;
     return 11;
 }
 int scatter_tile(long m_total, int N) {
-    if (N > 64 && mg_cdiv(m_total, 64) * mg_cdiv(N, 128) >= 384) return 12;
+    if (const char* f = getenv("MG_FORCE_TILE"))
+        if (atoi(f) == 12 && N > 64) return 12;
+    (void)m_total;
     return 11;
 }
 
