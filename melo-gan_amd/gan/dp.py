@@ -49,3 +49,28 @@ class DataParallel:
 
     def allreduce_g(self):
         self._allreduce(self.engine.GE.grad)
+
+    # ---- overlapped variant for the generator step --------------------------------------------------------
+    # decoder.pre.2.weight is 89 % of the G+E_num gradient bytes and is final ~100 us before the end of backward
+    # (SURVEY hard part 5).  start_g_big() launches its all-reduce asynchronously (RCCL runs on its own stream,
+    # ordered after the launching stream) while the caller enqueues the rest of backward; finish_g() all-reduces
+    # the two small remaining slices and waits for the big one.
+    def start_g_big(self):
+        if self.world == 1 or self.dist is None:
+            return
+        off, n = self.engine.big_grad_slice()
+        self._pending.append(self.dist.all_reduce(self.engine.GE.grad[off:off + n], op=self.dist.ReduceOp.SUM,
+                                                  group=self.group, async_op=True))
+
+    def finish_g(self):
+        if self.world == 1 or self.dist is None:
+            return
+        off, n = self.engine.big_grad_slice()
+        g = self.engine.GE.grad
+        if off > 0:
+            self._allreduce(g[:off])
+        if off + n < g.numel():
+            self._allreduce(g[off + n:])
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()

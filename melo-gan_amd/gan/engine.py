@@ -525,6 +525,14 @@ class GanEngine:
         self.draw_randoms(with_alpha=False)
         self.g_backward()
 
+    def g_backward_a_rng(self):
+        self.draw_randoms(with_alpha=False)
+        self.g_backward_a()
+
+    def big_grad_slice(self):
+        """(offset, numel) of decoder.pre.2.weight's gradient inside the flat G+E_num gradient buffer."""
+        return self.GE.offsets["G.decoder.pre.2.weight"]
+
     def d_update(self):
         ops.adam_flat(self.D.data, self.D.grad, self.D.m, self.D.v, self.D.state, self.lr_d, *self.betas,
                       grad_scale=1.0 / self.world_size)
@@ -533,9 +541,14 @@ class GanEngine:
     # G-step  (src/gan/train_gan.py:211-251)
     # -------------------------------------------------------------------------------------
     def g_backward(self):
+        self.g_backward_a()
+        self.g_backward_b()
+
+    def g_backward_a(self):
+        """G-step up to and including decoder.pre.2's weight gradient (89 % of the G+E_num gradient bytes): the
+        data-parallel wrapper starts that slice's all-reduce here and overlaps it with g_backward_b."""
         B = self.B
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
-        PE, GEg = self._ep, (lambda k: self.GE.g["E." + k])
         if not self._ed_folded:
             self.fold_ed()
         self._e_fwd(train=True)
@@ -579,8 +592,14 @@ class GanEngine:
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
         ops.act_bwd(self.d_p2, self.d_p2, gref=self.a_p2, gact=ACT_RELU)
+        ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"))
+        self._join()
+
+    def g_backward_b(self):
+        B = self.B
+        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
+        PE, GEg = self._ep, (lambda k: self.GE.g["E." + k])
         with self._branch(1):
-            ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"))
             ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
         with self._branch(0):
@@ -647,7 +666,7 @@ class GanEngine:
             self._graphs[name] = g
             st = g
         st.launch()
-        if name in ("d_backward", "g_backward", "d_backward_rng", "g_backward_rng"):
+        if name in ("d_backward", "g_backward", "d_backward_rng", "g_backward_rng", "g_backward_a", "g_backward_a_rng"):
             self.num_batches_tracked += 1
 
     # -------------------------------------------------------------------------------------

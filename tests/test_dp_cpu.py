@@ -39,14 +39,20 @@ def _worker(rank, port, out):
     torch.set_num_threads(1)
     fd, fg = shard_grads(rank)
     params = torch.full((8,), float(rank))
+    big = (1000, 5000)                      # stand-in for decoder.pre.2.weight's slice of the flat gradient
     eng = types.SimpleNamespace(D=types.SimpleNamespace(grad=fd.clone(), data=params.clone()),
-                                GE=types.SimpleNamespace(grad=fg.clone(), data=params.clone() + 1), world_size=1)
+                                GE=types.SimpleNamespace(grad=fg.clone(), data=params.clone() + 1), world_size=1,
+                                big_grad_slice=lambda: big)
     dp = DataParallel(eng, WORLD, dist)
     dp.broadcast_params()
     assert eng.world_size == WORLD
     assert torch.equal(eng.D.data, torch.zeros(8)) and torch.equal(eng.GE.data, torch.ones(8))   # rank 0's values
     dp.allreduce_d()
-    dp.allreduce_g()
+    g_plain = eng.GE.grad.clone()
+    dist.all_reduce(g_plain)
+    dp.start_g_big()                        # overlapped variant: big slice async, then the two remainders
+    dp.finish_g()
+    assert torch.equal(eng.GE.grad, g_plain)
     if rank == 0:
         torch.save({"d": eng.D.grad / WORLD, "g": eng.GE.grad / WORLD}, out)
     dist.destroy_process_group()
