@@ -301,6 +301,47 @@ def ae_case(name, B, T, latent_dim=8, n_steps=2):
     print(name, "loss", [out[f"s{i}.loss"] for i in range(n_steps)])
 
 
+def midi_case(name):
+    """Output contract (SURVEY f-1): the note events save_piano_roll_to_midi (src/gan/utils.py:95-161) derives from
+    a generated (T, 4) tensor.  pretty_midi is absent, so a recording stand-in for the four names the function uses
+    captures the Note objects it creates; the SMF byte serialisation itself (pretty_midi.write) is NOT pinned."""
+    rec = {}
+
+    class Note:
+        def __init__(self, velocity, pitch, start, end):
+            self.velocity, self.pitch, self.start, self.end = velocity, pitch, start, end
+
+    class Instrument:
+        def __init__(self, program):
+            self.program, self.notes = program, []
+
+    class PrettyMIDI:
+        def __init__(self, initial_tempo=120.0):
+            rec["tempo"] = initial_tempo
+            self.instruments = []
+
+        def write(self, path):
+            rec["notes"] = [(n.velocity, n.pitch, n.start, n.end) for n in self.instruments[0].notes]
+            rec["program"] = self.instruments[0].program
+
+    pm = sys.modules["pretty_midi"]
+    pm.Note, pm.Instrument, pm.PrettyMIDI = Note, Instrument, PrettyMIDI
+    pm.instrument_name_to_program = lambda nm: {"Acoustic Grand Piano": 0, "Violin": 40}[nm]
+    from src.gan.utils import save_piano_roll_to_midi
+    g = torch.Generator().manual_seed(11)
+    roll = (torch.rand(96, 4, generator=g) * 2.4 - 1.2).numpy().astype(np.float32)   # beyond [-1,1] to hit the clips
+    out = dict(roll=roll)
+    for tag, kw in (("a", dict(bpm=120.0, scale="major", root_key=0)),
+                    ("b", dict(bpm=200.0, scale="minor_pentatonic", root_key=7, instrument_name="Violin")),
+                    ("c", dict(bpm=45.0, scale="not_a_scale", root_key=3))):
+        save_piano_roll_to_midi(roll, "/dev/null", **kw)
+        out[f"{tag}.notes"] = np.array(rec["notes"], dtype=np.float64)
+        out[f"{tag}.tempo"] = np.float64(rec["tempo"])
+        out[f"{tag}.program"] = np.int64(rec["program"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.endswith("notes")})
+
+
 if __name__ == "__main__":
     gan_case("gan_c128_t64_b4", 4, 64, 128)                    # cfg1 shape at B=4
     gan_case("gan_c4_t32_b4", 4, 32, 4)                        # reference shape (C=4) scaled down
@@ -310,3 +351,4 @@ if __name__ == "__main__":
     layers_case("layers_c4_t16_b2", 2, 16, 4)
     layers_case("layers_c128_t32_b2", 2, 32, 128)
     ae_case("ae_t32_b4", 4, 32)
+    midi_case("midi_events")
