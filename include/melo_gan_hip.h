@@ -115,12 +115,14 @@ int mg_conv_tile_config(long m_rows, int N, int scatter2);
  *   ConvT1d  wgrad: S=x  (A=Cin),  L=dy (Bc=Cout) -> (Cin,Cout,K)
  *   Linear   wgrad: Ts=Tl=1,K=1: S=dy (A=out), L=x (Bc=in) -> (out,in)
  * Up to two (S,L,nb) segments are summed (segment 1 may have nb1=0).
+ * Fused bias gradient (optional): bias_from = 1 -> bias_out[a] = sum of S over segment 0's rows (Conv1d / Linear
+ * bias); bias_from = 2 -> bias_out[b] = sum of L over segment 0's rows (ConvTranspose1d bias); 0/NULL -> none.
  * `work` must hold mg_wgrad_workspace_bytes(...) bytes.  Deterministic (no atomics).
  */
 size_t mg_wgrad_workspace_bytes(int A, int Bc, int K, int nb_total, int Ts);
 int mg_wgrad(const float* s0, const float* l0, int nb0,
              const float* s1, const float* l1, int nb1,
-             float* out, int Ts, int Tl, int A, int Bc, int K, int stride,
+             float* out, float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride,
              void* work, size_t work_bytes, mg_stream_t stream);
 
 /* ---- per-channel column reductions over rows of a (R, C) matrix ----

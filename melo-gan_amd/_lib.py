@@ -27,7 +27,7 @@ SIGNATURES = {
     "mg_linear": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_conv_tile_config": (i32, [i64, i32, i32]),
     "mg_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
-    "mg_wgrad": (i32, [vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "mg_wgrad": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "mg_colsum_workspace_bytes": (sz, [i32]),
     "mg_colsum": (i32, [vp, i64, i32, vp, vp, vp, sz, vp]),
     "mg_bn_workspace_bytes": (sz, [i32]),

@@ -162,8 +162,7 @@ class VaeEngine:
         ins = [self.y0, self.da_[0], self.da_[1]]
         for j in (2, 1, 0):
             i = DEC[j][0]
-            ops.colsum(dn, g[f"decoder.deconv.{i}.bias"])
-            ops.convT1d_wgrad(ins[j], dn, g[f"decoder.deconv.{i}.weight"])
+            ops.convT1d_wgrad(ins[j], dn, g[f"decoder.deconv.{i}.weight"], db=g[f"decoder.deconv.{i}.bias"])
             if j == 0:
                 ops.convT1d_dgrad(dn, p[f"decoder.deconv.{i}.weight"], self.g_y0)
                 break
@@ -174,22 +173,17 @@ class VaeEngine:
             dn = self.g_dz[j - 1]
         ops.transpose_bcl_blc(self.g_y0, self.g_p2.view(B, 128, self.red))
         ops.act_bwd(self.g_p2, self.g_p2, gref=self.p2, gact=ACT_RELU)
-        ops.linear_wgrad(self.p0, self.g_p2, g["decoder.pre.2.weight"])
-        ops.colsum(self.g_p2, g["decoder.pre.2.bias"])
+        ops.linear_wgrad(self.p0, self.g_p2, g["decoder.pre.2.weight"], db=g["decoder.pre.2.bias"])
         ops.linear_dgrad(self.g_p2, p["decoder.pre.2.weight"], self.g_p0, gref=self.p0, gact=ACT_RELU)
-        ops.linear_wgrad(self.zl, self.g_p0, g["decoder.pre.0.weight"])
-        ops.colsum(self.g_p0, g["decoder.pre.0.bias"])
+        ops.linear_wgrad(self.zl, self.g_p0, g["decoder.pre.0.weight"], db=g["decoder.pre.0.bias"])
         ops.linear_dgrad(self.g_p0, p["decoder.pre.0.weight"], self.g_z)
         ops.reparam_bwd(self.g_z, self.lv, self.eps, self.k_mu, self.k_lv, self.g_mu, self.g_lv)
-        ops.linear_wgrad(self.h, self.g_mu, g["fc_mu.weight"])
-        ops.colsum(self.g_mu, g["fc_mu.bias"])
-        ops.linear_wgrad(self.h, self.g_lv, g["fc_log_var.weight"])
-        ops.colsum(self.g_lv, g["fc_log_var.bias"])
+        ops.linear_wgrad(self.h, self.g_mu, g["fc_mu.weight"], db=g["fc_mu.bias"])
+        ops.linear_wgrad(self.h, self.g_lv, g["fc_log_var.weight"], db=g["fc_log_var.bias"])
         ops.linear_dgrad(self.g_mu, p["fc_mu.weight"], self.g_h)
         ops.linear_dgrad(self.g_lv, p["fc_log_var.weight"], self.g_h, accumulate=True)
         ops.act_bwd(self.g_h, self.g_h, gref=self.h, gact=ACT_RELU)
-        ops.linear_wgrad(self.flat, self.g_h, g["encoder._linear.1.weight"])
-        ops.colsum(self.g_h, g["encoder._linear.1.bias"])
+        ops.linear_wgrad(self.flat, self.g_h, g["encoder._linear.1.weight"], db=g["encoder._linear.1.bias"])
         ops.linear_dgrad(self.g_h, p["encoder._linear.1.weight"], self.g_flat)
         ops.transpose_bcl_blc(self.g_flat.view(B, 128, self.Lenc), self.g_ea[2])      # back to (B, L, 128)
         ins = [self.x, self.ea[0], self.ea[1]]
@@ -198,8 +192,7 @@ class VaeEngine:
             nm = f"encoder.conv.{i + 1}"
             ops.bn_train_bwd(self.g_ea[j], self.ea[j], self.ez[j], self.g_ez[j], p[nm + ".weight"], self.e_mean[j],
                              self.e_istd[j], g[nm + ".weight"], g[nm + ".bias"], ACT_RELU)
-            ops.colsum(self.g_ez[j], g[f"encoder.conv.{i}.bias"])
-            ops.conv1d_wgrad(ins[j], self.g_ez[j], g[f"encoder.conv.{i}.weight"], 2)
+            ops.conv1d_wgrad(ins[j], self.g_ez[j], g[f"encoder.conv.{i}.weight"], 2, db=g[f"encoder.conv.{i}.bias"])
             if j > 0:
                 ops.conv1d_dgrad(self.g_ez[j], p[f"encoder.conv.{i}.weight"], self.g_ea[j - 1], 2)
 

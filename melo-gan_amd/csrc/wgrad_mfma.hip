@@ -22,7 +22,10 @@ struct WgradP {
     int bps;        // batch groups per split
     int n_bgroups;  // total batch groups (over both segments)
     int nbg0;       // batch groups in segment 0
-    long slab;      // A*Bc*K
+    long slab;      // A*Bc*K (+ bias entries): stride between partial slabs
+    long wslab;     // A*Bc*K
+    int bias_from;  // 0: none; 1: column sums of S (Conv1d / Linear bias); 2: column sums of L (ConvTranspose1d bias)
+    int nseg_bias;  // how many segments contribute to the bias (penalty segment never does)
     int vec_ok;     // all four tensors 16-byte aligned and < 2 GiB (raw-buffer float4 path)
 };
 
@@ -73,6 +76,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
         }
     };
 
+    // bias gradient fused in: per chunk every thread adds its share of the staged rows' column sums
+    float bsum = 0.f;
+    const bool do_bias_s = p.bias_from == 1 && blockIdx.y == 0;
+    const bool do_bias_l = p.bias_from == 2 && blockIdx.x == 0;
+    auto bias_accum = [&](int boff, int seg_id) {
+        if (seg_id >= p.nseg_bias) return;
+        const float* Ss = smem + boff;
+        const float* Ls = Ss + RT * BA;
+        const int cx = tid & 63, rq = tid >> 6;
+        if (do_bias_s) {
+#pragma unroll
+            for (int r = rq; r < RT; r += 4) bsum += Ss[r * BA + cx];
+        } else if (do_bias_l) {
+            // each L row belongs to exactly one chunk: window rows [PAD, PAD + TT*S) of every segment
+            for (int seg = 0; seg < TB; ++seg)
+                for (int rr = PAD + rq; rr < PAD + TT * S; rr += 4) bsum += Ls[(seg * R + rr) * BB + cx];
+        }
+    };
     const bool fast = ((p.A & 3) == 0) && ((p.Bc & 3) == 0) && p.vec_ok && (lrows * (BB / 4) <= 256 * NL4);
     if (fast) {
         // Software pipeline as in conv_mfma.hip: the next chunk's S rows and L window are fetched with
@@ -132,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
             for (int c = 0; c < n_chunks; ++c) {
                 const bool more = c + 1 < n_chunks;
                 if (more) load_chunk(c + 1);
+                bias_accum(cur, (g_begin + c / p.n_ttiles) < p.nbg0 ? 0 : 1);
                 compute(cur);
                 if (more) store_chunk(buf_floats - cur);
                 __syncthreads();
@@ -169,9 +191,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
                 Ls[row * BB + cl] = v;
             }
             __syncthreads();
+            bias_accum(0, seg_id);
             compute(0);
         }
     }
+    }
+    if (do_bias_s || do_bias_l) {        // 4 row-lane partials -> one value per channel of this tile
+        __syncthreads();
+        float* red = smem;
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            const int ch = (do_bias_s ? a0 : b0) + tid;
+            if (ch < (do_bias_s ? p.A : p.Bc))
+                p.part[(long)split * p.slab + p.wslab + ch] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+        }
     }
     float* out = p.part + (long)split * p.slab;
     const int b = b0 + wb * 32 + (lane & 31);
@@ -186,9 +220,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     }
 }
 
-// out[i] = sum_z part[z][i]; 64 elements x 4 slice-groups per block (fixed summation order => reproducible)
+// out[i] = sum_z part[z][i]; 64 elements x 4 slice-groups per block (fixed summation order => reproducible).
+// Elements [0, wn) go to `out` (weight gradient), elements [wn, n) to `bias_out`.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           long n, int nsplit) {
+                                                           float* __restrict__ bias_out, long n, long wn, int nsplit) {
     __shared__ float sh[4][64];
     const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + ex;
@@ -197,7 +232,11 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         for (int z = g; z < nsplit; z += 4) s += part[(long)z * n + i];
     sh[g][ex] = s;
     __syncthreads();
-    if (g == 0 && i < n) out[i] = (sh[0][ex] + sh[1][ex]) + (sh[2][ex] + sh[3][ex]);
+    if (g == 0 && i < n) {
+        const float v = (sh[0][ex] + sh[1][ex]) + (sh[2][ex] + sh[3][ex]);
+        if (i < wn) out[i] = v;
+        else bias_out[i - wn] = v;
+    }
 }
 
 struct Plan {
@@ -231,25 +270,29 @@ Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
 }  // namespace
 
 extern "C" size_t mg_wgrad_workspace_bytes(int A, int Bc, int K, int nb_total, int Ts) {
+    // (includes room for a fused bias gradient of max(A, Bc) entries per slab)
     // upper bound over any (nb0, nb1) split of nb_total: nsplit <= min(64, #batch groups)
     int lg = mg_ilog2_ceil(Ts);
     if (lg > 5) lg = 5;
     const int TB = RT >> lg;
     long ns = mg_cdiv(nb_total, TB) + 1;
     if (ns > 64) ns = 64;
-    return (size_t)ns * (size_t)A * (size_t)Bc * (size_t)K * sizeof(float);
+    return (size_t)ns * ((size_t)A * (size_t)Bc * (size_t)K + (size_t)(A > Bc ? A : Bc)) * sizeof(float);
 }
 
 extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* s1, const float* l1, int nb1,
-                        float* out, int Ts, int Tl, int A, int Bc, int K, int stride, void* work,
-                        size_t work_bytes, mg_stream_t stream) {
+                        float* out, float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride,
+                        void* work, size_t work_bytes, mg_stream_t stream) {
+    MG_CHECK_ARG(bias_from >= 0 && bias_from <= 2 && ((bias_from == 0) == (bias_out == nullptr)),
+                 "mg_wgrad: bias_out and bias_from (1: sums of S, 2: sums of L) must be given together");
     MG_CHECK_ARG(s0 && l0 && out && nb0 > 0, "mg_wgrad: null/empty segment 0");
     MG_CHECK_ARG(nb1 == 0 || (s1 && l1), "mg_wgrad: null segment 1");
     MG_CHECK_ARG(Ts > 0 && Tl > 0 && A > 0 && Bc > 0, "mg_wgrad: bad shape");
     MG_CHECK_ARG(K == 1 || K == 3 || K == 5, "mg_wgrad: K=%d unsupported", K);
     MG_CHECK_ARG(stride == 1 || stride == 2, "mg_wgrad: stride=%d unsupported", stride);
     const Plan pl = make_plan(A, Bc, K, nb0, nb1, Ts);
-    const long slab = (long)A * Bc * K;
+    const long wslab = (long)A * Bc * K;
+    const long slab = wslab + (bias_from == 1 ? A : bias_from == 2 ? Bc : 0);
     if (!work || work_bytes < (size_t)pl.nsplit * slab * sizeof(float)) {
         mg_set_error("mg_wgrad: workspace too small (%zu < %zu)", work_bytes, (size_t)pl.nsplit * slab * sizeof(float));
         return MG_EWORK;
@@ -262,6 +305,9 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     p.tt_log2 = pl.tt_log2; p.n_ttiles = pl.n_ttiles;
     p.bps = pl.bps; p.n_bgroups = pl.nbg0 + pl.nbg1; p.nbg0 = pl.nbg0;
     p.slab = slab;
+    p.wslab = wslab;
+    p.bias_from = bias_from;
+    p.nseg_bias = 1;      // only segment 0 (the loss term) carries a bias gradient; the penalty segment has none
     const int TT = 1 << pl.tt_log2;
     const int R = (TT - 1) * stride + K;
     const size_t lds = 2 * ((size_t)RT * BA + (size_t)pl.TB * R * BB) * sizeof(float);
@@ -282,7 +328,7 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
 #undef MG_WG
     MG_CHECK_LAUNCH("wgrad_kernel");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(slab, 64)), dim3(256), 0, st,
-                       (const float*)work, out, slab, pl.nsplit);
+                       (const float*)work, out, bias_out, slab, wslab, pl.nsplit);
     MG_CHECK_LAUNCH("reduce_slabs_kernel");
     return MG_OK;
 }

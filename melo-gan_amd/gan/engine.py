@@ -498,20 +498,19 @@ class GanEngine:
         # becomes launchable as soon as its tangent exists, so they run on side streams next to the tangent pass
         # (d(lambda*gp)/d(grad_xhat) pushed forward through the masked linear critic).
         with self._branch(0):
-            ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:])
-            ops.colsum(self.dZ1[:2 * B], G["conv.0.bias"])
-            ops.colsum(self.dZ2[:2 * B], G["conv.2.bias"])
-            ops.colsum(self.dZ3[:2 * B], G["conv.4.bias"])
-            ops.colsum(self.dU[:2 * B], G["fc.1.bias"])
+            ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:],
+                             db=G["conv.0.bias"])
         ops.conv1d_fwd(self.TAN0, P["conv.0.weight"], self.TAN1, 2, gref=self.A1[2 * B:], gact=ACT_LRELU)
         with self._branch(1):
-            ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:])
+            ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:],
+                             db=G["conv.2.bias"])
         ops.conv1d_fwd(self.TAN1, P["conv.2.weight"], self.TAN2, 2, gref=self.A2[2 * B:], gact=ACT_LRELU)
         ops.conv1d_fwd(self.TAN2, P["conv.4.weight"], self.TZ3, 2, gref=self.A3[2 * B:], gact=ACT_LRELU)
-        ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:])
+        ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:],
+                         db=G["conv.4.bias"])
         ops.meanT_fwd(self.TZ3, self.ghb)
         ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[2 * B:], gact=ACT_LRELU)
-        ops.linear_wgrad(self.H[:2 * B], self.dU[:2 * B], G["fc.1.weight"], self.ghb, self.dU[2 * B:])
+        ops.linear_wgrad(self.H[:2 * B], self.dU[:2 * B], G["fc.1.weight"], self.ghb, self.dU[2 * B:], db=G["fc.1.bias"])
         ops.dhead_wgrad(self.ds_d, self.Fh, self.emb, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"], 2 * B, B)
         ops.wgan_d_loss(self.s, self.gp, self.lambda_gp, self.loss_d_out, B)
         self._join()
@@ -574,61 +573,50 @@ class GanEngine:
             ops.copy_cols(self.dnotes.view(B, -1), 0, self.dn_dense.view(B, -1), 0, self.L3 * self.C)
             dn = self.dn_dense
         with self._branch(0):
-            ops.colsum(dn, GG("decoder.deconv.6.bias"))
-            ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"))
+            ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"))
         ops.convT1d_dgrad(dn, PG("decoder.deconv.6.weight"), self.d_ad3)
         ops.bn_train_bwd(self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, PG("decoder.deconv.4.weight"), self.bn_mean[1],
                          self.bn_invstd[1], GG("decoder.deconv.4.weight"), GG("decoder.deconv.4.bias"), ACT_RELU)
         with self._branch(1):
-            ops.colsum(self.d_zd3, GG("decoder.deconv.3.bias"))
-            ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"))
+            ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"))
         ops.convT1d_dgrad(self.d_zd3, PG("decoder.deconv.3.weight"), self.d_ad0)
         ops.bn_train_bwd(self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, PG("decoder.deconv.1.weight"), self.bn_mean[0],
                          self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
         with self._branch(0):
-            ops.colsum(self.d_zd0, GG("decoder.deconv.0.bias"))
-            ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"))
+            ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"))
         ops.convT1d_dgrad(self.d_zd0, PG("decoder.deconv.0.weight"), self.d_y0)
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
         ops.act_bwd(self.d_p2, self.d_p2, gref=self.a_p2, gact=ACT_RELU)
-        ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"))
+        ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"))
         self._join()
 
     def g_backward_b(self):
         B = self.B
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         PE, GEg = self._ep, (lambda k: self.GE.g["E." + k])
-        with self._branch(1):
-            ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
         with self._branch(0):
-            ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"))
-            ops.colsum(self.d_p0, GG("decoder.pre.0.bias"))
+            ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"))
         ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
         if self.ed_mode != "notes":
             ops.axpby(self.ed_dfeat, self.d_lat, 1.0, 1.0)
         with self._branch(1):
-            ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"))
-            ops.colsum(self.d_lat, GG("noise_to_latent.net.2.bias"))
+            ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"), db=GG("noise_to_latent.net.2.bias"))
         ops.linear_dgrad(self.d_lat, PG("noise_to_latent.net.2.weight"), self.d_n0, gref=self.a_n0, gact=ACT_RELU)
         with self._branch(0):
-            ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"))
-            ops.colsum(self.d_n0, GG("noise_to_latent.net.0.bias"))
+            ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"), db=GG("noise_to_latent.net.0.bias"))
         ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
         # embedding gradient = generator-input slice + critic-head path, then E_num backward
         ops.copy_cols(self.d_gin, self.noise_dim, self.demb, 0, self.E, accumulate=True)
         with self._branch(1):
-            ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"))
-            ops.colsum(self.demb, GEg("net.7.bias"))
+            ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"), db=GEg("net.7.bias"))
         ops.linear_dgrad(self.demb, PE("net.7.weight"), self.d_ez2, gref=self.e_z2, gact=ACT_GELU, emul=self.dmask[1])
         with self._branch(0):
-            ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"))
-            ops.colsum(self.d_ez2, GEg("net.4.bias"))
+            ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"), db=GEg("net.4.bias"))
         ops.linear_dgrad(self.d_ez2, PE("net.4.weight"), self.d_ez1, gref=self.e_z1, gact=ACT_GELU, emul=self.dmask[0])
         with self._branch(1):
-            ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"))
-            ops.colsum(self.d_ez1, GEg("net.1.bias"))
+            ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"), db=GEg("net.1.bias"))
         ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
         ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
         self._join()

@@ -255,8 +255,10 @@ def workspace(nbytes: int, device, tag: str = "default") -> Tensor:
 
 
 def wgrad(small: Tensor, large: Tensor, out: Tensor, K: int, stride: int,
-          small2: Optional[Tensor] = None, large2: Optional[Tensor] = None, work: Optional[Tensor] = None):
-    """out[a][b][k] = sum S[bt,u,a] * L[bt,u*stride+k-(K-1)/2,b] over one or two (S, L) segments."""
+          small2: Optional[Tensor] = None, large2: Optional[Tensor] = None, work: Optional[Tensor] = None,
+          bias_out: Optional[Tensor] = None, bias_from: int = 0):
+    """out[a][b][k] = sum S[bt,u,a] * L[bt,u*stride+k-(K-1)/2,b] over one or two (S, L) segments; optionally the
+    bias gradient of segment 0 in the same launch (bias_from 1: column sums of S, 2: of L)."""
     _chk(small, "small")
     _chk(large, "large")
     _chk(out, "out")
@@ -276,6 +278,12 @@ def wgrad(small: Tensor, large: Tensor, out: Tensor, K: int, stride: int,
         nb1 = small2.shape[0]
         if tuple(small2.shape[1:]) != (Ts, A) or tuple(large2.shape) != (nb1, Tl, Bc):
             raise ValueError("wgrad: segment 1 shape mismatch")
+    if bias_out is not None:
+        _chk(bias_out, "bias_out", (A if bias_from == 1 else Bc,))
+        if bias_from not in (1, 2):
+            raise ValueError("wgrad: bias_from must be 1 (S) or 2 (L) when bias_out is given")
+    elif bias_from:
+        raise ValueError("wgrad: bias_from without bias_out")
     lib = L.load()
     need = lib.mg_wgrad_workspace_bytes(A, Bc, K, nb0 + nb1, Ts)
     if work is None:
@@ -283,30 +291,30 @@ def wgrad(small: Tensor, large: Tensor, out: Tensor, K: int, stride: int,
     if work.numel() * work.element_size() < need:
         raise ValueError("wgrad: workspace too small")
     with _observe(lambda: f"wgrad_kernel<{stride},{K}>", 2.0 * (nb0 + nb1) * Ts * A * Bc * K):
-        rc = lib.mg_wgrad(_p(small), _p(large), nb0, _p(small2), _p(large2), nb1, _p(out), Ts, Tl, A, Bc, K, stride,
-                          _p(work), work.numel() * work.element_size(), _stream())
+        rc = lib.mg_wgrad(_p(small), _p(large), nb0, _p(small2), _p(large2), nb1, _p(out), _p(bias_out), bias_from,
+                          Ts, Tl, A, Bc, K, stride, _p(work), work.numel() * work.element_size(), _stream())
     L.check(rc, "mg_wgrad")
     return out
 
 
-def conv1d_wgrad(x, dy, dw, stride, x2=None, dy2=None):
-    """dw (Cout, Cin, K) for nn.Conv1d: S = dy, L = x."""
+def conv1d_wgrad(x, dy, dw, stride, x2=None, dy2=None, db=None):
+    """dw (Cout, Cin, K) for nn.Conv1d: S = dy, L = x; db (Cout) = column sums of dy (segment 0) if given."""
     K = dw.shape[2]
-    return wgrad(dy, x, dw, K, stride, dy2, x2)
+    return wgrad(dy, x, dw, K, stride, dy2, x2, bias_out=db, bias_from=1 if db is not None else 0)
 
 
-def convT1d_wgrad(x, dy, dw):
-    """dw (Cin, Cout, 5) for the stride-2 ConvTranspose1d: S = x, L = dy."""
-    return wgrad(x, dy, dw, 5, 2)
+def convT1d_wgrad(x, dy, dw, db=None):
+    """dw (Cin, Cout, 5) for the stride-2 ConvTranspose1d: S = x, L = dy; db (Cout) = column sums of dy if given."""
+    return wgrad(x, dy, dw, 5, 2, bias_out=db, bias_from=2 if db is not None else 0)
 
 
-def linear_wgrad(x, dy, dw, x2=None, dy2=None):
-    """dw (out, in) = dy^T @ x (+ second segment)."""
+def linear_wgrad(x, dy, dw, x2=None, dy2=None, db=None):
+    """dw (out, in) = dy^T @ x (+ second segment); db (out) = column sums of dy (segment 0) if given."""
     B = x.shape[0]
     s2 = l2 = None
     if x2 is not None:
         s2, l2 = dy2.view(dy2.shape[0], 1, -1), x2.view(x2.shape[0], 1, -1)
-    return wgrad(dy.view(B, 1, -1), x.view(B, 1, -1), dw, 1, 1, s2, l2)
+    return wgrad(dy.view(B, 1, -1), x.view(B, 1, -1), dw, 1, 1, s2, l2, bias_out=db, bias_from=1 if db is not None else 0)
 
 
 # ---------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ def test_bad_arguments_are_rejected_on_the_host():
     lib = _lib.load()
     rc = lib.mg_conv1d_gather(None, None, None, 1, 1, 1, 1, 5, 1, 0, 5, 1, 0, 0, None, None, 0, None)
     assert rc == -1 and b"null" in lib.mg_last_error()
-    rc = lib.mg_wgrad(None, None, 0, None, None, 0, None, 1, 1, 1, 1, 1, 1, None, 0, None)
+    rc = lib.mg_wgrad(None, None, 0, None, None, 0, None, None, 0, 1, 1, 1, 1, 1, 1, None, 0, None)
     assert rc == -1
     assert lib.mg_wgrad_workspace_bytes(64, 64, 5, 8, 32) > 0
 

@@ -73,13 +73,14 @@ def test_conv1d_fwd_dgrad_wgrad(ops, B, T, Cin, Cout, K, stride):
     dx = torch.empty(B, T, Cin, device="cuda")
     ops.conv1d_dgrad(dz, wd, dx, stride)
     assert_close(dx, dx_ref.permute(0, 2, 1).contiguous(), atol=1e-4 if Cout * K > 1000 else ATOL)
-    dw = torch.empty(Cout, Cin, K, device="cuda")
-    ops.conv1d_wgrad(xd, dz, dw, stride)
+    dw, dbf = torch.empty(Cout, Cin, K, device="cuda"), torch.empty(Cout, device="cuda")
+    ops.conv1d_wgrad(xd, dz, dw, stride, db=dbf)             # bias gradient fused into the wgrad launch
     scale = dw_ref.abs().max().item()
     assert_close(dw, dw_ref, rtol=1e-4, atol=2e-5 * max(1.0, scale))
     db = torch.empty(Cout, device="cuda")
     ops.colsum(dz, db)
     assert_close(db, dz_ref.sum(dim=(0, 2)), rtol=1e-4, atol=1e-4)
+    assert_close(dbf, dz_ref.sum(dim=(0, 2)), rtol=1e-4, atol=1e-4)
 
 
 CONVT_CASES = [(3, 8, 256, 128), (2, 16, 128, 64), (2, 32, 64, 128), (3, 4, 64, 4), (64, 32, 256, 128), (64, 128, 64, 128)]
@@ -102,9 +103,10 @@ def test_convT1d_fwd_dgrad_wgrad(ops, B, T, Cin, Cout):
     dx = torch.empty(B, T, Cin, device="cuda")
     ops.convT1d_dgrad(dyd, wd, dx)
     assert_close(dx, dx_ref.permute(0, 2, 1).contiguous(), atol=1e-4)
-    dw = torch.empty(Cin, Cout, 5, device="cuda")
-    ops.convT1d_wgrad(xd, dyd, dw)
+    dw, db = torch.empty(Cin, Cout, 5, device="cuda"), torch.empty(Cout, device="cuda")
+    ops.convT1d_wgrad(xd, dyd, dw, db=db)
     assert_close(dw, dw_ref, rtol=1e-4, atol=2e-5 * max(1.0, dw_ref.abs().max().item()))
+    assert_close(db, dy.sum(dim=(0, 1)), rtol=1e-4, atol=1e-4)
 
 
 def test_convT1d_padded_output(ops):
@@ -139,9 +141,10 @@ def test_linear_fwd_dgrad_wgrad(ops, B, inf, outf):
     dx = torch.empty(B, inf, device="cuda")
     ops.linear_dgrad(dz, wd, dx)
     assert_close(dx, dx_ref, atol=1e-4)
-    dw = torch.empty(outf, inf, device="cuda")
-    ops.linear_wgrad(xd, dz, dw)
+    dw, db = torch.empty(outf, inf, device="cuda"), torch.empty(outf, device="cuda")
+    ops.linear_wgrad(xd, dz, dw, db=db)
     assert_close(dw, dw_ref, atol=1e-4)
+    assert_close(db, dz_ref.sum(dim=0), rtol=1e-4, atol=1e-4)
 
 
 def test_epilogue_chain_and_accumulate(ops):
