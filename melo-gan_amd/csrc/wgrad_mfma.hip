@@ -3,11 +3,18 @@
 //
 //   out[a][b][k] = sum_{segments, batch, u}  S[batch, u, a] * L[batch, u*stride + k - (K-1)/2, b]
 //
-// i.e. for every tap k a GEMM  Out_k = S^T (A x r) * L_k (r x Bc)  whose reduction index r runs
-// over (batch, time).  A workgroup owns a 64(a) x 64(b) x K output tile and one slice of the
-// batches; per 32-row r-chunk it stages S rows and the L window in LDS, and each wave keeps
-// K accumulators (32x32 per tap).  Slices write partial slabs; mg_wgrad's second kernel sums
-// them in a fixed order, so the result is bitwise reproducible (no float atomics).
+// i.e. for every tap k a GEMM  Out_k = S^T (A x r) * L_k (r x Bc)  whose reduction index r runs over
+// (batch, time).  Weight matrices are small (A, Bc <= 256) while r is long (up to 24576 rows), so the
+// parallelism has to come from the reduction:
+//   * a workgroup owns a 32(a) x 32(b) x K output tile and one slice of the batches;
+//   * per 64-row r-chunk it stages the S rows and the L window in LDS (raw-buffer float4 prefetch of the
+//     next chunk while the current one is multiplied) and its FOUR WAVES SPLIT THE CHUNK'S ROWS, each
+//     keeping K accumulators (32x32 per tap) for the same output tile;
+//   * at the end the four waves' accumulators are added through LDS, and slices write partial slabs that
+//     reduce_slabs_kernel sums in a fixed order -- bitwise reproducible, no float atomics.
+// Compared with a 64x64 tile per workgroup this gives 4x the workgroups per slab (e.g. the critic's
+// conv.0: 8 tiles x 32 slices = 256 workgroups with 32 slabs instead of 2 x 64 = 128 with 64 slabs).
+// The bias gradient (column sums of S or of L) can ride along in the same launch.
 #include "common.h"
 
 namespace {
@@ -29,8 +36,8 @@ struct WgradP {
     int vec_ok;     // all four tensors 16-byte aligned and < 2 GiB (raw-buffer float4 path)
 };
 
-constexpr int RT = 32;   // reduction rows per LDS chunk
-constexpr int BA = 64, BB = 64;
+constexpr int RT = 64;            // reduction rows per LDS chunk (16 per wave)
+constexpr int BA = 32, BB = 32;   // output tile per workgroup
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,11 +49,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     constexpr int NL4 = (RMAX * (BB / 4) + 255) / 256 + 1; // float4 prefetch slots for L
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wa = wave >> 1, wb = wave & 1;
     const int TT = 1 << p.tt_log2, TB = RT >> p.tt_log2;
     const int R = (TT - 1) * S + K;
     const int lrows = TB * R;
-    const int buf_floats = RT * BA + lrows * BB;           // {S rows, L window}; two buffers are allocated
+    float* Ss = smem;                    // [RT][BA]
+    float* Ls = smem + RT * BA;          // [TB*R][BB]
     const int a0 = blockIdx.x * BA, b0 = blockIdx.y * BB;
     const int split = blockIdx.z;
 
@@ -61,15 +68,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     const int g_end = min(g_begin + p.bps, p.n_bgroups);
     const int n_chunks = (g_end - g_begin) * p.n_ttiles;
 
-    auto compute = [&](int boff) {
-        const float* Ss = smem + boff;
-        const float* Ls = Ss + RT * BA;
+    // this wave's quarter of the chunk: rows [wave*16, wave*16+16)
+    auto compute = [&]() {
 #pragma unroll
-        for (int r2 = 0; r2 < RT / 2; ++r2) {
-            const int r = 2 * r2 + h;
+        for (int r2 = 0; r2 < RT / 8; ++r2) {
+            const int r = wave * (RT / 4) + 2 * r2 + h;
             const int seg = r >> p.tt_log2, tl = r & (TT - 1);
-            const float av = Ss[r * BA + wa * 32 + (lane & 31)];
-            const float* lrow = Ls + (seg * R + tl * S) * BB + wb * 32 + (lane & 31);
+            const float av = Ss[r * BA + (lane & 31)];
+            const float* lrow = Ls + (seg * R + tl * S) * BB + (lane & 31);
 #pragma unroll
             for (int k = 0; k < K; ++k)
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lrow[k * BB], acc[k], 0, 0, 0);
@@ -80,25 +86,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     float bsum = 0.f;
     const bool do_bias_s = p.bias_from == 1 && blockIdx.y == 0;
     const bool do_bias_l = p.bias_from == 2 && blockIdx.x == 0;
-    auto bias_accum = [&](int boff, int seg_id) {
+    auto bias_accum = [&](int seg_id) {
         if (seg_id >= p.nseg_bias) return;
-        const float* Ss = smem + boff;
-        const float* Ls = Ss + RT * BA;
-        const int cx = tid & 63, rq = tid >> 6;
+        const int cx = tid & 31, rq = tid >> 5;      // 32 channels x 8 row lanes
         if (do_bias_s) {
 #pragma unroll
-            for (int r = rq; r < RT; r += 4) bsum += Ss[r * BA + cx];
+            for (int r = rq; r < RT; r += 8) bsum += Ss[r * BA + cx];
         } else if (do_bias_l) {
             // each L row belongs to exactly one chunk: window rows [PAD, PAD + TT*S) of every segment
             for (int seg = 0; seg < TB; ++seg)
-                for (int rr = PAD + rq; rr < PAD + TT * S; rr += 4) bsum += Ls[(seg * R + rr) * BB + cx];
+                for (int rr = PAD + rq; rr < PAD + TT * S; rr += 8) bsum += Ls[(seg * R + rr) * BB + cx];
         }
     };
+
     const bool fast = ((p.A & 3) == 0) && ((p.Bc & 3) == 0) && p.vec_ok && (lrows * (BB / 4) <= 256 * NL4);
     if (fast) {
-        // Software pipeline as in conv_mfma.hip: the next chunk's S rows and L window are fetched with
-        // raw-buffer float4 loads (out-of-range slots return 0 in hardware) while the current chunk's MFMAs
-        // run out of the other LDS buffer; one barrier per chunk.
+        // the next chunk's S rows and L window are fetched with raw-buffer float4 loads (out-of-range slots
+        // return 0 in hardware) while the current chunk is multiplied; single LDS buffer, two barriers per chunk
         float4 sr[NS4], lr[NL4];
         auto load_chunk = [&](int c) {
             const int g = g_begin + c / p.n_ttiles, tt = c - (c / p.n_ttiles) * p.n_ttiles;
@@ -134,9 +138,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
                 lr[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
             }
         };
-        auto store_chunk = [&](int boff) {
-            float* Ss = smem + boff;
-            float* Ls = Ss + RT * BA;
+        auto store_chunk = [&]() {
 #pragma unroll
             for (int j = 0; j < NS4; ++j) *reinterpret_cast<float4*>(Ss + 4 * (tid + 256 * j)) = sr[j];
 #pragma unroll
@@ -147,75 +149,88 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
         };
         if (n_chunks > 0) {
             load_chunk(0);
-            store_chunk(0);
+            store_chunk();
             __syncthreads();
-            int cur = 0;
             for (int c = 0; c < n_chunks; ++c) {
                 const bool more = c + 1 < n_chunks;
                 if (more) load_chunk(c + 1);
-                bias_accum(cur, (g_begin + c / p.n_ttiles) < p.nbg0 ? 0 : 1);
-                compute(cur);
-                if (more) store_chunk(buf_floats - cur);
+                bias_accum((g_begin + c / p.n_ttiles) < p.nbg0 ? 0 : 1);
+                compute();
                 __syncthreads();
-                cur = buf_floats - cur;
+                if (more) {
+                    store_chunk();
+                    __syncthreads();
+                }
             }
         }
     } else {
-    float* Ss = smem;                 // [RT][BA]
-    float* Ls = smem + RT * BA;       // [TB*R][BB]
-    for (int g = g_begin; g < g_end; ++g) {
-        const int seg_id = g < p.nbg0 ? 0 : 1;
-        const int bg = seg_id ? g - p.nbg0 : g;
-        const float* Sp = p.s[seg_id];
-        const float* Lp = p.l[seg_id];
-        const int nb = p.nb[seg_id];
-        const int bb0 = bg * TB;
-        for (int tt = 0; tt < p.n_ttiles; ++tt) {
-            const int t0 = tt * TT;
-            const int tl0 = t0 * S - PAD;
-            __syncthreads();
-            for (int idx = tid; idx < RT * BA; idx += 256) {
-                const int r = idx / BA, al = idx - r * BA;
-                const int seg = r >> p.tt_log2, tl = r & (TT - 1);
-                const int b = bb0 + seg, t = t0 + tl, a = a0 + al;
-                float v = 0.f;
-                if (b < nb && t < p.Ts && a < p.A) v = Sp[((long)b * p.Ts + t) * p.A + a];
-                Ss[r * BA + al] = v;
+        for (int g = g_begin; g < g_end; ++g) {
+            const int seg_id = g < p.nbg0 ? 0 : 1;
+            const int bg = seg_id ? g - p.nbg0 : g;
+            const float* Sp = p.s[seg_id];
+            const float* Lp = p.l[seg_id];
+            const int nb = p.nb[seg_id];
+            const int bb0 = bg * TB;
+            for (int tt = 0; tt < p.n_ttiles; ++tt) {
+                const int t0 = tt * TT;
+                const int tl0 = t0 * S - PAD;
+                __syncthreads();
+                for (int idx = tid; idx < RT * BA; idx += 256) {
+                    const int r = idx / BA, al = idx - r * BA;
+                    const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+                    const int b = bb0 + seg, t = t0 + tl, a = a0 + al;
+                    float v = 0.f;
+                    if (b < nb && t < p.Ts && a < p.A) v = Sp[((long)b * p.Ts + t) * p.A + a];
+                    Ss[r * BA + al] = v;
+                }
+                for (int idx = tid; idx < TB * R * BB; idx += 256) {
+                    const int row = idx / BB, cl = idx - row * BB;
+                    const int seg = row / R, rr = row - seg * R;
+                    const int b = bb0 + seg, t = tl0 + rr, c = b0 + cl;
+                    float v = 0.f;
+                    if (b < nb && t >= 0 && t < p.Tl && c < p.Bc) v = Lp[((long)b * p.Tl + t) * p.Bc + c];
+                    Ls[row * BB + cl] = v;
+                }
+                __syncthreads();
+                bias_accum(seg_id);
+                compute();
             }
-            for (int idx = tid; idx < TB * R * BB; idx += 256) {
-                const int row = idx / BB, cl = idx - row * BB;
-                const int seg = row / R, rr = row - seg * R;
-                const int b = bb0 + seg, t = tl0 + rr, c = b0 + cl;
-                float v = 0.f;
-                if (b < nb && t >= 0 && t < p.Tl && c < p.Bc) v = Lp[((long)b * p.Tl + t) * p.Bc + c];
-                Ls[row * BB + cl] = v;
-            }
-            __syncthreads();
-            bias_accum(0, seg_id);
-            compute(0);
         }
     }
-    }
-    if (do_bias_s || do_bias_l) {        // 4 row-lane partials -> one value per channel of this tile
+
+    // ---- add the four waves' accumulators tap by tap through LDS and write this slice's partial slab ----
+    __syncthreads();
+    float* red = smem;                                   // [4][32][33] floats = 16.9 KB (fits: RT*BA + window >= 2K+..)
+    float* out = p.part + (long)split * p.slab;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 33 + (lane & 31)] = acc[k][r];
         __syncthreads();
-        float* red = smem;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            const int ar = idx >> 5, bc = idx & 31;
+            const int a = a0 + ar, b = b0 + bc;
+            if (a < p.A && b < p.Bc) {
+                const float v = (red[(0 * 32 + ar) * 33 + bc] + red[(1 * 32 + ar) * 33 + bc]) +
+                                (red[(2 * 32 + ar) * 33 + bc] + red[(3 * 32 + ar) * 33 + bc]);
+                out[((long)a * p.Bc + b) * K + k] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (do_bias_s || do_bias_l) {        // 8 row-lane partials -> one value per channel of this tile
         red[tid] = bsum;
         __syncthreads();
-        if (tid < 64) {
+        if (tid < 32) {
             const int ch = (do_bias_s ? a0 : b0) + tid;
-            if (ch < (do_bias_s ? p.A : p.Bc))
-                p.part[(long)split * p.slab + p.wslab + ch] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
-        }
-    }
-    float* out = p.part + (long)split * p.slab;
-    const int b = b0 + wb * 32 + (lane & 31);
-    if (b < p.Bc) {
+            if (ch < (do_bias_s ? p.A : p.Bc)) {
+                float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int a = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (a >= p.A) continue;
-#pragma unroll
-            for (int k = 0; k < K; ++k) out[((long)a * p.Bc + b) * K + k] = acc[k][r];
+                for (int g = 0; g < 8; ++g) v += red[tid + 32 * g];
+                out[p.wslab + ch] = v;
+            }
         }
     }
 }
@@ -243,10 +258,13 @@ struct Plan {
     int tt_log2, TB, n_ttiles, nbg0, nbg1, nsplit, bps;
 };
 
+constexpr int MAX_SPLITS = 32;
+
 Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
     Plan pl;
     int lg = mg_ilog2_ceil(Ts);
-    if (lg > 5) lg = 5;
+    const int lgrt = mg_ilog2_ceil(RT);
+    if (lg > lgrt) lg = lgrt;
     pl.tt_log2 = lg;
     pl.TB = RT >> lg;
     pl.n_ttiles = (int)mg_cdiv(Ts, 1 << lg);
@@ -254,13 +272,13 @@ Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
     pl.nbg1 = nb1 > 0 ? (int)mg_cdiv(nb1, pl.TB) : 0;
     const int ngroups = pl.nbg0 + pl.nbg1;
     const long tiles = mg_cdiv(A, BA) * mg_cdiv(Bc, BB);
-    // aim for ~512 workgroups, at least 2 r-chunks per split, at most 64 slabs
-    long want = mg_cdiv(512, tiles);
+    // aim for ~768 workgroups (3 per CU), at least 2 r-chunks per split, at most MAX_SPLITS slabs
+    long want = mg_cdiv(768, tiles);
     long max_by_work = ((long)ngroups * pl.n_ttiles) / 2;
     if (max_by_work < 1) max_by_work = 1;
     if (want > max_by_work) want = max_by_work;
     if (want > ngroups) want = ngroups;
-    if (want > 64) want = 64;
+    if (want > MAX_SPLITS) want = MAX_SPLITS;
     if (want < 1) want = 1;
     pl.bps = (int)mg_cdiv(ngroups, want);
     pl.nsplit = (int)mg_cdiv(ngroups, pl.bps);
@@ -270,13 +288,14 @@ Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
 }  // namespace
 
 extern "C" size_t mg_wgrad_workspace_bytes(int A, int Bc, int K, int nb_total, int Ts) {
-    // (includes room for a fused bias gradient of max(A, Bc) entries per slab)
-    // upper bound over any (nb0, nb1) split of nb_total: nsplit <= min(64, #batch groups)
+    // upper bound over any (nb0, nb1) split of nb_total: nsplit <= min(MAX_SPLITS, #batch groups);
+    // includes room for a fused bias gradient of max(A, Bc) entries per slab
     int lg = mg_ilog2_ceil(Ts);
-    if (lg > 5) lg = 5;
+    const int lgrt = mg_ilog2_ceil(RT);
+    if (lg > lgrt) lg = lgrt;
     const int TB = RT >> lg;
     long ns = mg_cdiv(nb_total, TB) + 1;
-    if (ns > 64) ns = 64;
+    if (ns > MAX_SPLITS) ns = MAX_SPLITS;
     return (size_t)ns * ((size_t)A * (size_t)Bc * (size_t)K + (size_t)(A > Bc ? A : Bc)) * sizeof(float);
 }
 
@@ -310,7 +329,9 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     p.nseg_bias = 1;      // only segment 0 (the loss term) carries a bias gradient; the penalty segment has none
     const int TT = 1 << pl.tt_log2;
     const int R = (TT - 1) * stride + K;
-    const size_t lds = 2 * ((size_t)RT * BA + (size_t)pl.TB * R * BB) * sizeof(float);
+    size_t lds_floats = (size_t)RT * BA + (size_t)pl.TB * R * BB;
+    if (lds_floats < 4 * 32 * 33) lds_floats = 4 * 32 * 33;     // the final cross-wave reduction reuses the buffer
+    const size_t lds = lds_floats * sizeof(float);
     {
         auto ok = [](const float* q, long elems) { return q == nullptr || (((((uintptr_t)q) & 15) == 0) && elems * 4 < (1L << 31)); };
         p.vec_ok = ok(s0, (long)nb0 * Ts * A) && ok(l0, (long)nb0 * Tl * Bc) && ok(nb1 ? s1 : nullptr, (long)nb1 * Ts * A) &&
