@@ -262,9 +262,14 @@ class GanEngine:
         self._graphs = {}
         # hipGraph capture is illegal on the null stream: every step runs on this side stream
         self.stream = torch.cuda.Stream(device=d)
-        # side streams: independent branches of a step (weight gradients next to the data-gradient chain, the
-        # critic next to the emotion discriminator) run concurrently and are captured as parallel graph branches
+        # Side streams for independent branches of a step (weight gradients next to the data-gradient chain, the
+        # critic next to the emotion discriminator), captured as parallel graph branches.  MEASURED (round 1, cfg2):
+        # single-stream graphs are fastest -- 1.695 ms/step vs 1.73 (critic branch only) vs 1.82 (all branches):
+        # once the kernels themselves fill the chip, every fork/join costs more cross-queue latency than the
+        # overlap returns.  Default is therefore "none"; MELO_BRANCH=all|big|critic re-enables them.
         self.side = [torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)]
+        import os
+        self.branch_mode = os.environ.get("MELO_BRANCH", "none")
         self.world_size = 1
         self._ed_folded = False
 
@@ -466,9 +471,15 @@ class GanEngine:
         ops.conv1d_dgrad(self.ed_dz[0], P["encoder.conv.0.net.0.weight"], dnotes, 1)
 
     @contextmanager
-    def _branch(self, i: int):
+    def _branch(self, i: int, small: bool = False, critic: bool = False):
         """Run the enclosed launches on side stream i, ordered after everything enqueued so far on the
-        current stream (fork).  _join() makes the current stream wait for the side streams again."""
+        current stream (fork).  _join() makes the current stream wait for the side streams again.
+        `small` marks branches that only hold a few microseconds of work (MELO_BRANCH=big keeps those inline,
+        MELO_BRANCH=none disables all side streams)."""
+        if self.branch_mode == "none" or (small and self.branch_mode in ("big", "critic")) or \
+                (self.branch_mode == "critic" and not critic):
+            yield
+            return
         s = self.side[i]
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -553,7 +564,7 @@ class GanEngine:
         self._e_fwd(train=True)
         self._g_fwd(self.notes, train=True)
         # the critic branch (forward + input gradient) runs beside the emotion-discriminator branch
-        with self._branch(0):
+        with self._branch(0, critic=True):
             self._d_fwd(self.notes, B)
             ops.neg_mean(self.s[:B], self.adv)
             self._d_bwd_input(self.ds_g, B, self.demb)
@@ -596,26 +607,26 @@ class GanEngine:
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         PE, GEg = self._ep, (lambda k: self.GE.g["E." + k])
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
-        with self._branch(0):
+        with self._branch(0, small=True):
             ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"))
         ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
         if self.ed_mode != "notes":
             ops.axpby(self.ed_dfeat, self.d_lat, 1.0, 1.0)
-        with self._branch(1):
+        with self._branch(1, small=True):
             ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"), db=GG("noise_to_latent.net.2.bias"))
         ops.linear_dgrad(self.d_lat, PG("noise_to_latent.net.2.weight"), self.d_n0, gref=self.a_n0, gact=ACT_RELU)
-        with self._branch(0):
+        with self._branch(0, small=True):
             ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"), db=GG("noise_to_latent.net.0.bias"))
         ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
         # embedding gradient = generator-input slice + critic-head path, then E_num backward
         ops.copy_cols(self.d_gin, self.noise_dim, self.demb, 0, self.E, accumulate=True)
-        with self._branch(1):
+        with self._branch(1, small=True):
             ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"), db=GEg("net.7.bias"))
         ops.linear_dgrad(self.demb, PE("net.7.weight"), self.d_ez2, gref=self.e_z2, gact=ACT_GELU, emul=self.dmask[1])
-        with self._branch(0):
+        with self._branch(0, small=True):
             ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"), db=GEg("net.4.bias"))
         ops.linear_dgrad(self.d_ez2, PE("net.4.weight"), self.d_ez1, gref=self.e_z1, gact=ACT_GELU, emul=self.dmask[0])
-        with self._branch(1):
+        with self._branch(1, small=True):
             ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"), db=GEg("net.1.bias"))
         ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
         ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
