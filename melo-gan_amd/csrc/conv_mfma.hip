@@ -435,9 +435,11 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     const long total = (long)p.B * p.Tout * p.N;
     p.ksplit = 1;
     p.cps = nchunks;
-    if (p.work && n_wgs < 192 && nchunks >= 4) {
+    long wg_target = 256, wg_max = 192;
+    if (const char* f = getenv("MG_SPLITK_TARGET")) { wg_target = atol(f); wg_max = wg_target * 3 / 4; }
+    if (p.work && n_wgs < wg_max && nchunks >= 4) {
         int ks = 1;
-        while (ks < 8 && n_wgs * ks < 256 && nchunks / (ks * 2) >= 2) ks *= 2;
+        while (ks < 8 && n_wgs * ks < wg_target && nchunks / (ks * 2) >= 2) ks *= 2;
         if (ks > 1 && p.work_bytes >= (size_t)ks * total * sizeof(float)) {
             p.ksplit = ks;
             p.cps = (int)mg_cdiv(nchunks, ks);
