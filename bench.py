@@ -224,9 +224,19 @@ def main():
             ops.set_launch_hook(None)
             sm = hook.summary().get(DOMINANT)
             if sm:
+                # HBM bytes per launch of this kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
+                # WRITE_SIZE passes, gfx950 correction applied): measured offline, committed under profiles/
+                traffic = None
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r01_traffic_dominant_kernel.json")) as f:
+                        tj = json.load(f)
+                    if tj.get("kernel") == DOMINANT:
+                        traffic = round(tj["traffic_bytes_per_launch"])
+                except (OSError, ValueError, KeyError):
+                    pass
                 achieved = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, kernel=DOMINANT,
+                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, kernel=DOMINANT,
                             launches=sm["launches"], avg_us=round(1e3 * sm["ms"] / sm["launches"], 2),
                             avg_gflop_per_launch=round(sm["flops"] / sm["launches"] / 1e9, 3))
         loss_d, adv, emo = eng.loss_d_out[0].item(), eng.adv.item(), eng.emo.item()
