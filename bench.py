@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for the roofline leg")
+    ap.add_argument("--workload", default="gan", choices=["gan", "ae", "gen1"],
+                    help="gan: the headline cfg2 step (default); ae: BASELINE config 4 (VAE step, B=256, T=256, C=4); "
+                         "gen1: BASELINE config 5 (batch-1 E_num->G generation latency)")
     return ap.parse_args()
 
 
@@ -125,8 +128,73 @@ def cpu_baseline(seconds: float):
                        f"torch {torch.__version__} CPU, {el:.1f} s")
 
 
+def side_workload(args):
+    """Secondary BASELINE configs (single GPU, not the headline metric): one JSON line each."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    torch.cuda.set_device(0)
+    if args.workload == "ae":
+        from melo_gan_amd.ae.engine import VaeEngine
+        Bv, Tv = 256, 256
+        eng = VaeEngine(dict(MAX_NOTES=Tv, LATENT_DIM=8, BATCH_SIZE=Bv, LR=1e-4, WEIGHT_DECAY=1e-5), "cuda", Bv)
+        eng.init_weights(0)
+        x = torch.rand(Bv, Tv, 4, device="cuda") * 2 - 1
+        eps = torch.empty(Bv, 8, device="cuda")
+        with torch.cuda.stream(eng.stream):
+            def one():
+                eng.step(x, eps.normal_(), 10.0)
+            for _ in range(max(args.warmup, 3)):
+                one()
+            torch.cuda.synchronize()
+            g = ops.Graph()
+            g.begin()
+            eng.forward(True); eng.backward(10.0); eng.update()
+            g.end()
+            g.launch(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eps.normal_()
+                eng.eps.copy_(eps)
+                g.launch()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        print(json.dumps({"metric": "VAE samples/sec (ae_config step), batch=256 T=256 C=4", "value": round(Bv * args.steps / el, 1),
+                          "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "cfg4: VAE step B=256, T=256, C=4, latent 8, beta 10"},
+                          "losses": {"total": round(eng.loss[0].item(), 5)}}), flush=True)
+        return
+    from melo_gan_amd.gan.engine import GanEngine
+    from melo_gan_amd.gan.config import default_gan_cfg, default_ed_cfg
+    for (Tg, Cg) in ((512, 4), (256, 128)):
+        eng = GanEngine(default_gan_cfg(1, Tg, Cg), default_ed_cfg(Cg), "cuda", 1)
+        eng.init_weights(42)
+        z, num = torch.randn(1, 128, device="cuda"), torch.randn(1, 6, device="cuda")
+        with torch.cuda.stream(eng.stream):
+            for _ in range(5):
+                eng.generate(z, num)
+            torch.cuda.synchronize()
+            g = ops.Graph()
+            g.begin()
+            eng._e_fwd(train=False); eng._g_fwd(eng.notes, train=False)
+            g.end()
+            lat = []
+            for _ in range(1000):
+                eng.noise.copy_(z)
+                t0 = time.perf_counter()
+                g.launch()
+                out = eng.notes[0, 0, 0].item()          # D2H of the result = end of the request (app.py:105)
+                lat.append(time.perf_counter() - t0)
+        lat.sort()
+        print(json.dumps({"metric": "batch-1 generation latency (E_num -> G, eval)", "value": round(1e6 * lat[500], 1), "unit": "us p50",
+                          "p99_us": round(1e6 * lat[990], 1), "n_gpus": 1, "steps": 1000, "higher_is_better": False, "dtype": "f32",
+                          "config": {"workload": f"cfg5: B=1, T={Tg}, C={Cg}, hipGraph replay + 4-byte D2H sync"}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload != "gan":
+        return side_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
