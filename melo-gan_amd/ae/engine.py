@@ -14,7 +14,7 @@ import torch
 
 from .. import ops
 from ..gan.engine import FlatParams, BN_EPS, BN_MOM
-from ..ops import ACT_NONE, ACT_RELU, ACT_TANH
+from ..ops import ACT_RELU, ACT_TANH
 
 ENC = ((0, 4, 32), (3, 32, 64), (6, 64, 128))       # (index in encoder.conv, Cin, Cout)
 DEC = ((0, 128, 64), (3, 64, 32), (6, 32, 4))       # (index in decoder.deconv, Cin, Cout)

@@ -14,9 +14,6 @@ testable without GPUs.
 """
 from __future__ import annotations
 
-from typing import Optional
-
-
 class DataParallel:
     def __init__(self, engine, world_size: int, dist=None, group=None):
         self.engine, self.world, self.dist, self.group = engine, int(world_size), dist, group

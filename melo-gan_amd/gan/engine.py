@@ -24,6 +24,7 @@ the oracle's draws and production runs fill the same buffers from the device RNG
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from contextlib import contextmanager
 from typing import Dict, Optional, Sequence
@@ -31,7 +32,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from .. import ops
-from ..ops import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU
+from ..ops import ACT_GELU, ACT_LRELU, ACT_RELU
 
 Tensor = torch.Tensor
 BN_EPS, BN_MOM, P_DROP = 1e-5, 0.1, 0.2
@@ -268,7 +269,6 @@ class GanEngine:
         # once the kernels themselves fill the chip, every fork/join costs more cross-queue latency than the
         # overlap returns.  Default is therefore "none"; MELO_BRANCH=all|big|critic re-enables them.
         self.side = [torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)]
-        import os
         self.branch_mode = os.environ.get("MELO_BRANCH", "none")
         self.world_size = 1
         self._ed_folded = False

@@ -96,7 +96,7 @@ def _conv_work(lib, B, Tout, N, Cin, device):
 
 
 def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_sn: int, w_sc: int,
-                flip: bool = False, y_rows: Optional[int] = None, **epi) -> Tensor:
+                flip: bool = False, **epi) -> Tensor:
     """Generic gather window-GEMM (see mg_conv1d_gather).  x: (B, Tin, Cin); y: (B, Ty, N) with
     Ty >= Tout (rows beyond Tout are left untouched -- the generator's zero-pad branch)."""
     _chk(x, "x")
