@@ -23,6 +23,19 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// -DMG_STAMPS: debug build that records wall-clock stamps (100 MHz) of workgroup phases; see scratch/stamps.py
+#ifdef MG_STAMPS
+__device__ long long* mg_stamp_buf = nullptr;
+#define MG_STAMP(k)                                                                                        \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && mg_stamp_buf)                                                              \
+            mg_stamp_buf[((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (k)] = \
+                wall_clock64();                                                                            \
+    } while (0)
+#else
+#define MG_STAMP(k)
+#endif
+
 struct ConvP {
     const float* x;
     const float* w;
@@ -62,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
+    MG_STAMP(0);
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -205,10 +219,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             }
         }
         long wg[NW4];
-        int wl[NW4];
+        int wl[NW4];     // LDS offset of the slot's first element inside the weight slab
+        int wk[NW4];     // CNK layout: tap index of that element (the 4 elements walk (n, k) in k-major order)
 #pragma unroll
         for (int j = 0; j < NW4; ++j) {
             const int e4 = tid + 256 * j;
+            wk[j] = 0;
             if (w_nck) {
                 constexpr int PER = BKC * K / 4;
                 const int n = e4 / PER, q = e4 - n * PER;
@@ -217,73 +233,148 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             } else {
                 constexpr int PER = BN * K / 4;
                 const int c = e4 / PER, q = e4 - c * PER;
+                const int n = (4 * q) / K, k = 4 * q - n * K;
                 wg[j] = (long)c * p.w_sc + (long)n0 * K + 4 * q;   // + c0*w_sc per chunk
-                wl[j] = c * K * SW + 4 * q;                  // decoded at store time: (c, nk = 4q+i)
+                wl[j] = (c * K + k) * SW + n;
+                wk[j] = k;
             }
         }
         float4 xr[MAXX], wr[NW4];
+        auto load_x = [&](int j, int c0) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo[j] + 4u * (unsigned)c0, 0, 0);
+            xr[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        };
+        auto load_w = [&](int j, long woff) { wr[j] = *reinterpret_cast<const float4*>(p.w + wg[j] + woff); };
+        auto w_off = [&](int c0) { return w_nck ? (long)c0 * K : (long)c0 * p.w_sc; };
+        auto store_x = [&](int j, float* d) {
+            d[0] = xr[j].x; d[1] = xr[j].y; d[2] = xr[j].z; d[3] = xr[j].w;
+        };
+        // the 4 elements of a weight float4 walk k within a column (NCK: next LDS row each time) or (n, k) pairs
+        // in k-major order (CNK: next row until the tap wraps, then the next column); one branch-free form
+        const int wrapk = w_nck ? -1 : K - 1;
+        auto store_w = [&](int j, float* Wb) {
+            const float v[4] = {wr[j].x, wr[j].y, wr[j].z, wr[j].w};
+            int d = wl[j], k = wk[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Wb[d] = v[i];
+                const bool wrap = (k == wrapk);
+                d += wrap ? 1 - (K - 1) * SW : SW;
+                k = wrap ? 0 : k + 1;
+            }
+        };
         auto load_chunk = [&](int c0) {
 #pragma unroll
-            for (int j = 0; j < MAXX; ++j) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo[j] + 4u * (unsigned)c0, 0, 0);
-                xr[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-            }
-            const long woff = w_nck ? (long)c0 * K : (long)c0 * p.w_sc;
+            for (int j = 0; j < MAXX; ++j) load_x(j, c0);
+            const long woff = w_off(c0);
 #pragma unroll
-            for (int j = 0; j < NW4; ++j) wr[j] = *reinterpret_cast<const float4*>(p.w + wg[j] + woff);
+            for (int j = 0; j < NW4; ++j) load_w(j, woff);
         };
         auto store_chunk = [&](int boff) {
-            float* Xb = Xs + boff;
-            float* Wb = Ws + boff;
 #pragma unroll
-            for (int j = 0; j < MAXX; ++j) {
-                if (xl[j] >= 0) {
-                    float* d = Xb + xl[j];
-                    d[0] = xr[j].x; d[1] = xr[j].y; d[2] = xr[j].z; d[3] = xr[j].w;
-                }
-            }
+            for (int j = 0; j < MAXX; ++j)
+                if (xl[j] >= 0) store_x(j, Xs + boff + xl[j]);
 #pragma unroll
-            for (int j = 0; j < NW4; ++j) {
-                const float v[4] = {wr[j].x, wr[j].y, wr[j].z, wr[j].w};
-                if (w_nck) {
+            for (int j = 0; j < NW4; ++j) store_w(j, Ws + boff);
+        };
+        load_chunk(c_begin);
+        MG_STAMP(1);
+        store_chunk(0);
+        if (p.dbuf) {
+            // Software-pipelined loop over two LDS buffers.  The next chunk's round trip (prefetched registers ->
+            // other LDS buffer -> reload the registers with the chunk after it) is cut into per-slot pieces that
+            // sit BETWEEN the MFMA steps of the current chunk: a wave issues in order and every MFMA waits for
+            // its predecessor (same accumulator), so staging placed after the chunk's MFMAs ran unoverlapped
+            // (1.28 us per chunk against 0.64 us of MFMA time, measured with -DMG_STAMPS); placed between them
+            // it rides in their shadow.  The body has no branches: past the end the last chunk is re-staged
+            // into the idle buffer, and slots without a row write to a per-thread dummy.
+            constexpr int NSTEP = BKC / 2;
+            const int c_last = c_end - BKC;
+            const int dummy = 2 * buf_floats + 4 * tid;
+            load_chunk(min(c_begin + BKC, c_last));
+            __syncthreads();
+            MG_STAMP(2);
+            int cur = 0;
+            for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
+                const int oth = buf_floats - cur;
+                const int cn = min(c0 + 2 * BKC, c_last);
+                const long wn_off = w_off(cn);
+                const float* Xb = Xs + cur;
+                const float* Wb = Ws + cur;
+                auto pieces = [&](int c2) {
+#ifndef MG_EXP_NOPIECES
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) Wb[wl[j] + i * SW] = v[i];
+                    for (int j = 0; j < MAXX; ++j)
+                        if (j % NSTEP == c2) {
+                            store_x(j, smem + (xl[j] >= 0 ? oth + xl[j] : dummy));
+#ifndef MG_EXP_NOLOADS
+                            load_x(j, cn);
+#endif
+                        }
+#pragma unroll
+                    for (int j = 0; j < NW4; ++j)
+                        if ((MAXX + j) % NSTEP == c2) {
+                            store_w(j, Ws + oth);
+#ifndef MG_EXP_NOLOADS
+                            load_w(j, wn_off);
+#endif
+                        }
+#endif
+                };
+                if constexpr (FRAG_DB) {
+                    float a0[NR][TM], b0[K][TN], a1[NR][TM], b1[K][TN];
+                    frag_load(Xb, Wb, 0, a0, b0);
+#pragma unroll
+                    for (int c2 = 0; c2 < NSTEP; c2 += 2) {
+                        frag_load(Xb, Wb, c2 + 1, a1, b1);
+                        frag_mma(a0, b0);
+                        pieces(c2);
+                        if (c2 + 2 < NSTEP) frag_load(Xb, Wb, c2 + 2, a0, b0);
+                        frag_mma(a1, b1);
+                        pieces(c2 + 1);
+                    }
                 } else {
-                    const int cbase = (wl[j] / (K * SW)) * (K * SW);
-                    const int nk0 = wl[j] - cbase;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int nk = nk0 + i, n = nk / K, k = nk - n * K;
-                        Wb[cbase + k * SW + n] = v[i];
+                    for (int c2 = 0; c2 < NSTEP; ++c2) {
+                        float a0[NR][TM], b0[K][TN];
+                        frag_load(Xb, Wb, c2, a0, b0);
+                        frag_mma(a0, b0);
+                        pieces(c2);
                     }
                 }
-            }
-        };
-        // double-buffered LDS: chunk i+1 is written to the other buffer right after chunk i's MFMAs,
-        // one barrier per chunk
-        load_chunk(c_begin);
-        store_chunk(0);
-        __syncthreads();
-        int cur = 0;
-        if (p.dbuf) {
-            for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
-                const bool more = c0 + BKC < c_end;
-                if (more) load_chunk(c0 + BKC);
-                compute(BKC / 2, cur);
-                if (more) store_chunk(buf_floats - cur);
                 __syncthreads();
-                cur = buf_floats - cur;
+                cur = oth;
+#ifdef MG_STAMPS
+                { const int it = (c0 - c_begin) / BKC; if (it < 2) MG_STAMP(8 + 4 * it); else if (it < 4) MG_STAMP(11 + it); }
+#endif
             }
         } else {
+            __syncthreads();
+            MG_STAMP(2);
             for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
                 const bool more = c0 + BKC < c_end;
+#ifdef MG_STAMPS
+                const int it = (c0 - c_begin) / BKC;
+#endif
                 if (more) load_chunk(c0 + BKC);
                 compute(BKC / 2, 0);
+#ifdef MG_STAMPS
+                if (it < 2) MG_STAMP(5 + 4 * it);
+#endif
                 __syncthreads();
+#ifdef MG_STAMPS
+                if (it < 2) MG_STAMP(6 + 4 * it);
+#endif
                 if (more) {
                     store_chunk(0);
+#ifdef MG_STAMPS
+                    if (it < 2) MG_STAMP(7 + 4 * it);
+#endif
                     __syncthreads();
                 }
+#ifdef MG_STAMPS
+                if (it < 2) MG_STAMP(8 + 4 * it); else if (it < 4) MG_STAMP(11 + it);
+#endif
             }
         }
     } else {
@@ -337,46 +428,108 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     }
 
     // ---- epilogue ----
+    // Written as whole-tile passes over the accumulator registers, each selected by ONE uniform branch: with the
+    // activation switch inside the per-element loop hipcc evaluated erff/tanhf for every element of every launch
+    // and selected afterwards (4 us of a 16-us workgroup on the B=64 layers).
+    MG_STAMP(3);
     const mg_epilogue& E = p.e;
+    const long slab = (long)p.B * p.Tout * p.N;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int n = n0 + wn * 32 * TN + ni * 32 + (lane & 31);
         if (n >= p.N) continue;
-        const float bias = E.bias ? E.bias[n] : 0.f;
-        const float scale = E.scale ? E.scale[n] : 1.f;
-        const float shift = E.scale ? E.shift[n] : 0.f;
-        const float gscale = E.gscale ? E.gscale[n] : 1.f;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int im = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int seg = im >> p.tt_log2, tl = im & (TT - 1);
-                const int b = b0 + seg, t = t0 + tl;
-                if (b >= p.B || t >= p.Tm) continue;
-#pragma unroll
-                for (int ph = 0; ph < NPH; ++ph) {
+            for (int ph = 0; ph < NPH; ++ph) {
+                f32x16& a = acc[ph][mi][ni];
+                // dense / strided output index of accumulator element r; false if the row is outside the tensor
+                auto index = [&](int r, unsigned& di, unsigned& yi) -> bool {
+                    const int im = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int seg = im >> p.tt_log2, tl = im & (TT - 1);
+                    const int b = b0 + seg, t = t0 + tl;
                     const int tout = TR2 ? 2 * t + ph : t;
-                    if (TR2 && tout >= p.Tout) continue;
-                    const long di = ((long)b * p.Tout + tout) * p.N + n;
-                    const long yi = (long)b * p.ybs + (long)tout * p.N + n;
-                    if (p.ksplit > 1) {      // raw partial sum; conv_finish_kernel adds the slabs and runs the epilogue
-                        p.part[(long)blockIdx.z * ((long)p.B * p.Tout * p.N) + di] = acc[ph][mi][ni][r];
-                        continue;
-                    }
-                    float v = acc[ph][mi][ni][r] + bias;
-                    v = v * scale + shift;
-                    if (E.zout) E.zout[di] = v;
-                    v = mg_act(E.act, v);
-                    if (E.gref) v *= mg_act_grad(E.gact, E.gref[di]);
-                    if (E.emul) v *= E.emul[di];
-                    v *= gscale;
-                    if (E.accumulate) v += p.y[yi];
-                    p.y[yi] = v;
+                    di = (unsigned)((b * p.Tout + tout) * p.N + n);      // host checked: both fit 31 bits
+                    yi = (unsigned)(b * (int)p.ybs + tout * p.N + n);
+                    return b < p.B && t < p.Tm && tout < p.Tout;
+                };
+                unsigned di, yi;
+                if (p.ksplit > 1) {      // raw partial sums; conv_finish_kernel adds the slabs and runs the epilogue
+                    float* dst = p.part + (long)blockIdx.z * slab;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (index(r, di, yi)) dst[di] = a[r];
+                    continue;
                 }
+                if (E.bias) {
+                    const float bias = E.bias[n];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] += bias;
+                }
+                if (E.scale) {
+                    const float scale = E.scale[n], shift = E.shift[n];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = a[r] * scale + shift;
+                }
+                if (E.zout) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (index(r, di, yi)) E.zout[di] = a[r];
+                }
+                if (E.act == MG_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = mg_act(MG_ACT_RELU, a[r]);
+                } else if (E.act == MG_ACT_LRELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = mg_act(MG_ACT_LRELU, a[r]);
+                } else if (E.act == MG_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = mg_act(MG_ACT_GELU, a[r]);
+                } else if (E.act == MG_ACT_TANH) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = mg_act(MG_ACT_TANH, a[r]);
+                }
+                if (E.gref) {
+                    if (E.gact == MG_ACT_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_RELU, E.gref[di]);
+                    } else if (E.gact == MG_ACT_LRELU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_LRELU, E.gref[di]);
+                    } else if (E.gact == MG_ACT_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_GELU, E.gref[di]);
+                    } else if (E.gact == MG_ACT_TANH) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_TANH, E.gref[di]);
+                    }
+                }
+                if (E.emul) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (index(r, di, yi)) a[r] *= E.emul[di];
+                }
+                if (E.gscale) {
+                    const float gscale = E.gscale[n];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] *= gscale;
+                }
+                if (E.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (index(r, di, yi)) a[r] += p.y[yi];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (index(r, di, yi)) p.y[yi] = a[r];
             }
         }
     }
+    MG_STAMP(4);
 }
 
 // sums the split-K slabs in fixed order and applies the fused epilogue
@@ -413,7 +566,7 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     // shape measured (e.g. 94.9 vs 85.6 TFLOP/s on the ED conv3 shape); MG_FORCE_DBUF=1 re-enables the double buffer
     p.dbuf = 0;
     if (const char* f = getenv("MG_FORCE_DBUF")) p.dbuf = atoi(f) ? 1 : 0;
-    const size_t lds = (p.dbuf ? 2 : 1) * lds1;
+    const size_t lds = p.dbuf ? 2 * lds1 + 256 * 4 * sizeof(float) : lds1;
     if (lds > 160 * 1024) {
         mg_set_error("conv_wgemm: LDS request %zu too large", lds);
         return MG_EUNSUP;
@@ -497,6 +650,12 @@ int fill_epilogue(ConvP& p, const mg_epilogue* epi) {
     } else {
         p.e = mg_epilogue{};
     }
+    // the kernel indexes outputs with 32-bit element offsets
+    const long dense = (long)p.B * p.Tout * p.N, strided = (long)(p.B - 1) * p.ybs + (long)p.Tout * p.N;
+    if (dense >= (1L << 31) || strided >= (1L << 31) || p.ybs >= (1L << 31)) {
+        mg_set_error("conv_wgemm: output of %ld (strided %ld) elements exceeds the 2^31 element limit", dense, strided);
+        return MG_EUNSUP;
+    }
     return MG_OK;
 }
 
@@ -558,6 +717,12 @@ extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int 
 // (22 = 128x128 tile, 11 = 64x64, 12 = 64x128 two-phase).  m_rows = B*Tout (gather) or B*Tin (scatter2).
 // workspace that lets the window GEMMs split the channel reduction over workgroups (<= 8 output-sized slabs)
 extern "C" size_t mg_conv_workspace_bytes(int B, int Tout, int N) { return (size_t)8 * B * Tout * N * sizeof(float); }
+
+#ifdef MG_STAMPS
+extern "C" int mg_dbg_set_stamps(long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(mg_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int mg_conv_tile_config(long m_rows, int N, int scatter2) {
     return scatter2 ? scatter_tile(m_rows, N) : gather_tile(m_rows, N);
