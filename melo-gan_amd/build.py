@@ -14,6 +14,8 @@ OUT = os.path.join(HERE, "libmelogan_hip.so")
 SOURCES = ["runtime.hip", "conv_mfma.hip", "linear_skinny.hip", "wgrad_mfma.hip", "small_kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+# conv_mfma.hip stores transposed weight quads as scalar pairs on purpose (see store_pair there)
+EXTRA_FLAGS = {"conv_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(a, b):
@@ -28,7 +30,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         op = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _newer(sp, op) or any(_newer(d, op) for d in deps):
-            jobs.append([HIPCC, *FLAGS, "-c", sp, "-o", op])
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

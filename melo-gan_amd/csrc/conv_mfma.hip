@@ -18,6 +18,7 @@
 // HBM -- bounds this kernel by a wide margin: 2 A + 2 B ds_read_b32 feed 4 MFMAs (256 cycles).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -43,11 +44,11 @@ struct ConvP {
     int B, Tin, Cin, Tm, Tout, N;
     long xbs, ybs;
     long x_bytes;    // extent of x in bytes if < 2^31 (buffer-descriptor range), else 0 => slow path
+    long w_bytes;    // same for w
     int w_sn, w_sc;
     int flip;
     int tt_log2;
     int n_ttiles;
-    int dbuf;         // 1: two LDS buffers, one barrier per chunk; 0: one buffer, two barriers (more WGs per CU)
     int ksplit;       // channel-chunk ranges handled by different workgroups (blockIdx.z); 1 => none
     int cps;          // chunks per split
     float* part;      // [ksplit][B*Tout*N] raw partial sums when ksplit > 1
@@ -59,23 +60,43 @@ struct ConvP {
 // channels per LDS chunk: 16 for K=3/5 taps, 64 for K=1 (Linear layers: fewer, fatter chunks)
 template <int K> struct ChunkOf { static constexpr int value = (K == 1) ? 64 : 16; };
 
-template <int S, int K, bool TR2, int TM, int TN>
+// LDS images (one chunk = BKC channels):
+//   window  Xs[row][SX]            SX = BKC + 4 floats: 16-B aligned rows whose pitch is an odd number of
+//                                  16-B granules, so the 16 lanes of a ds_read_b128 group hit 16 bank quads
+//   weights Ws[tap][quad][n][4]    quad = channel/4: the 4 channels of a quad are contiguous per output column
+// Every MFMA operand is read with ds_read_b128: lane (i, h = lane>>5) takes channel quad 2g+h of its row /
+// column, which feeds the 4 MFMAs s = 0..3 of channel group g (MFMA k-slot h <-> channel 8g + 4h + s on both
+// operands).  One 16-B read per 4 MFMAs instead of one 4-B read per MFMA: with a single wave per SIMD the 4-B
+// reads were latency-bound at ~13 cycles each and, not the matrix pipe, set the chunk time (MG_STAMPS runs).
+template <int S, int K, bool TR2, bool NCK, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     constexpr int BKC = ChunkOf<K>::value;
-    constexpr int SX = BKC + 1;    // padded LDS row stride of the input window (odd => conflict-free reads)
-    constexpr int BM = 64 * TM, BN = 64 * TN, SW = BN + 1;
+    constexpr int CG = BKC / 4;          // channel quads per chunk
+    constexpr int G8 = BKC / 8;          // MFMA groups per chunk
+    constexpr int SX = BKC + 4;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int WT = CG * BN * 4;      // floats per tap plane of the weight slab
     constexpr int SA = TR2 ? 1 : S;
     constexpr int NR = TR2 ? 3 : K;
     constexpr int NPH = TR2 ? 2 : 1;
     constexpr int PAD = (K - 1) / 2;
-    constexpr int XQ = BKC / 4;                                       // float4 per window row
+    constexpr int XQ = BKC / 4;                                        // float4 per window row
     constexpr int MAXX = (((BM - 1) * SA + NR) * XQ + 255) / 256 + 1;  // prefetch registers (float4) for X
-    constexpr int NW4 = BN * BKC * K / 4 / 256;                       // prefetch registers (float4) for W
-    static_assert((BN * BKC * K) % 1024 == 0, "weight slab must split evenly into float4 per thread");
+    // weight staging units per thread.  NCK (w[n][c][k]): unit = (column n, quad): 4K contiguous floats = K float4,
+    // transposed in registers into K 16-B stores.  CNK (w[c][n][k]): unit = (quad, float4 position in the (n,k)
+    // run): the same float4 of 4 consecutive channel rows, transposed into 4 16-B stores.
+    constexpr int UN = BN * CG / 256;
+    constexpr int P4 = BN * K / 4;
+    constexpr int UC = (CG * P4 + 255) / 256;
+    constexpr int NWR = NCK ? UN * K : UC * 4;
+    static_assert((BN * CG) % 256 == 0, "weight units must split evenly over the workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     MG_STAMP(0);
+#ifdef MG_STAMPS
+    const long long clk0 = clock64();
+#endif
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -83,10 +104,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     const int TB = BM >> p.tt_log2;
     const int R = (TT - 1) * SA + NR;
     const int nrows = TB * R;
-    const int xs_floats = (nrows * SX + 3) & ~3;
-    const int buf_floats = xs_floats + BKC * K * SW;     // one {X window, W slab} buffer; two are allocated
-    float* Xs = smem;
-    float* Ws = smem + xs_floats;
+    const int xs_floats = nrows * SX;
+    const int buf_floats = xs_floats + K * WT;           // one {window, weight slab} buffer
+    const int sink = 2 * buf_floats + 4 * tid;           // per-thread 16-B sink for staging slots without data
 
     const int mtile = blockIdx.x;
     const int b0 = (mtile / p.n_ttiles) * TB;
@@ -94,19 +114,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     const int n0 = blockIdx.y * BN;
     const int tin0 = TR2 ? (t0 - 1) : (t0 * S - PAD);
 
-    // per-lane operand bases
+    // every LDS offset used below is a multiple of 4 floats: tell hipcc, or it splits the 16-B accesses
+    auto lds4 = [&](int off) { return reinterpret_cast<f32x4*>(__builtin_assume_aligned(smem + off, 16)); };
+
+    // per-lane operand bases (float offsets inside a buffer)
     int abase[TM];
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int im = wm * 32 * TM + mi * 32 + (lane & 31);
         const int seg = im >> p.tt_log2, tl = im & (TT - 1);
-        abase[mi] = (seg * R + tl * SA) * SX + (lane >> 5);
+        abase[mi] = (seg * R + tl * SA) * SX + 4 * (lane >> 5);
     }
     int bbase[TN];
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) bbase[ni] = (lane >> 5) * K * SW + wn * 32 * TN + ni * 32 + (lane & 31);
-    const int kstep = p.flip ? -SW : SW;
-    const int kbase = p.flip ? (K - 1) * SW : 0;
+    for (int ni = 0; ni < TN; ++ni)
+        bbase[ni] = xs_floats + ((lane >> 5) * BN + wn * 32 * TN + ni * 32 + (lane & 31)) * 4;
 
     f32x16 acc[NPH][TM][TN];
 #pragma unroll
@@ -118,313 +140,300 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ph][mi][ni][r] = 0.f;
 
-    const bool vec_ok = ((p.Cin & 3) == 0) && ((p.xbs & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
     // split-K: this workgroup reduces over channels [c_begin, c_end) only
     const int c_begin = blockIdx.z * p.cps * BKC;
     const int c_end = min(p.Cin, c_begin + p.cps * BKC);
-    const bool w_nck = p.w_sc < p.w_sn;   // (c,k) contiguous for a fixed n
 
-    // one chunk of MFMAs out of LDS
-    // One chunk of MFMAs out of LDS.  The operand fragments of step c2+1 are read into a second
-    // register set BEFORE the MFMAs of step c2 issue, so the ~100-cycle ds_read latency hides under
-    // the matrix pipe even with a single wave per SIMD (without this, PMC showed 40 % of wave time
-    // parked in s_waitcnt lgkmcnt and the MFMA pipe only 33 % busy).
-    auto frag_load = [&](const float* Xb, const float* Wb, int c2, float (&a)[NR][TM], float (&bw)[K][TN]) {
+    // the MFMAs of channel group g (8 channels) out of the buffer at float offset boff
+    auto group_mma = [&](int boff, int g) {
+        f32x4 a[NR][TM], bw[K][TN];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) a[r][mi] = Xb[abase[mi] + r * SX + 2 * c2];
+            for (int mi = 0; mi < TM; ++mi)
+                a[r][mi] = *lds4(boff + abase[mi] + r * SX + 8 * g);
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) bw[k][ni] = Wb[bbase[ni] + 2 * c2 * K * SW + kbase + k * kstep];
-    };
-    auto frag_mma = [&](const float (&a)[NR][TM], const float (&bw)[K][TN]) {
-        if constexpr (!TR2) {
+            for (int ni = 0; ni < TN; ++ni)
+                bw[k][ni] = *lds4(boff + bbase[ni] + k * WT + 2 * g * BN * 4);
 #pragma unroll
-            for (int k = 0; k < K; ++k)
+        for (int s = 0; s < 4; ++s) {
+            if constexpr (!TR2) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+                            acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mi][s], bw[k][ni][s], acc[0][mi][ni], 0, 0, 0);
+            } else {
+                // phase 0 (t = 2u):   k=0 <- row u+1, k=2 <- row u, k=4 <- row u-1
+                // phase 1 (t = 2u+1): k=1 <- row u+1, k=3 <- row u
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mi], bw[k][ni], acc[0][mi][ni], 0, 0, 0);
-        } else {
-            // phase 0 (t = 2u):   k=0 <- row u+1, k=2 <- row u, k=4 <- row u-1
-            // phase 1 (t = 2u+1): k=1 <- row u+1, k=3 <- row u
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[0][ni], acc[0][mi][ni], 0, 0, 0);
-                    acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi], bw[1][ni], acc[1][mi][ni], 0, 0, 0);
-                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[2][ni], acc[0][mi][ni], 0, 0, 0);
-                    acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi], bw[3][ni], acc[1][mi][ni], 0, 0, 0);
-                    acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][mi], bw[4][ni], acc[0][mi][ni], 0, 0, 0);
-                }
-        }
-    };
-    constexpr bool FRAG_DB = !(K == 5 && TM * TN >= 2);   // the 5-tap wide tiles have no registers left for it
-    auto compute = [&](int nc2, int boff) {
-        const float* Xb = Xs + boff;
-        const float* Wb = Ws + boff;
-        if constexpr (FRAG_DB) {
-            float a0[NR][TM], b0[K][TN], a1[NR][TM], b1[K][TN];
-            frag_load(Xb, Wb, 0, a0, b0);
-            int c2 = 0;
-            for (; c2 + 2 <= nc2; c2 += 2) {
-                frag_load(Xb, Wb, c2 + 1, a1, b1);
-                frag_mma(a0, b0);
-                if (c2 + 2 < nc2) frag_load(Xb, Wb, c2 + 2, a0, b0);
-                frag_mma(a1, b1);
-            }
-            if (c2 < nc2) frag_mma(a0, b0);
-        } else {
-            for (int c2 = 0; c2 < nc2; ++c2) {
-                float a0[NR][TM], b0[K][TN];
-                frag_load(Xb, Wb, c2, a0, b0);
-                frag_mma(a0, b0);
+                    for (int ni = 0; ni < TN; ++ni) {
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi][s], bw[0][ni][s], acc[0][mi][ni], 0, 0, 0);
+                        acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][mi][s], bw[1][ni][s], acc[1][mi][ni], 0, 0, 0);
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi][s], bw[2][ni][s], acc[0][mi][ni], 0, 0, 0);
+                        acc[1][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][mi][s], bw[3][ni][s], acc[1][mi][ni], 0, 0, 0);
+                        acc[0][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][mi][s], bw[4][ni][s], acc[0][mi][ni], 0, 0, 0);
+                    }
             }
         }
     };
 
-    // Fast path: every chunk and this block's weight slab are full and 16-B aligned, so the next chunk's
-    // global loads are issued as float4 into registers BEFORE the current chunk's MFMAs and written to LDS
-    // after them -- HBM/L2 latency hides under the matrix pipe.
+    // Fast path: every chunk and this block's weight slab are full and 16-B aligned: the next chunk travels
+    // global -> registers (float4, issued a chunk ahead) -> LDS (16-B stores).
+    const bool vec_ok = ((p.Cin & 3) == 0) && ((p.xbs & 3) == 0) && ((((uintptr_t)p.x) & 15) == 0);
     const bool w_aligned = ((((uintptr_t)p.w) & 15) == 0) &&
-                           (w_nck ? (p.w_sc == K && (p.w_sn & 3) == 0) : (p.w_sn == K && (p.w_sc & 3) == 0));
+                           (NCK ? (p.w_sc == K && (p.w_sn & 3) == 0) : (p.w_sn == K && (p.w_sc & 3) == 0));
     const bool fast = vec_ok && w_aligned && (p.Cin % BKC == 0) && (n0 + BN <= p.N) && (nrows * XQ <= 256 * MAXX) &&
-                      p.x_bytes > 0;
+                      p.x_bytes > 0 && p.w_bytes > 0;
 
     if (fast) {
-        // chunk-invariant addressing of this thread's prefetch slots
-        // X loads go through a raw buffer descriptor: slots of out-of-range rows carry an offset beyond
+        // X and W loads go through raw buffer descriptors: slots of out-of-range rows carry an offset beyond
         // num_records, for which the hardware returns 0 -- no predicated load (hipcc branches and waits per
-        // slot) and no arithmetic on the loaded registers (hipcc hoists it above the MFMAs and waits there).
+        // slot) and no arithmetic on the loaded registers (hipcc hoists it above the MFMAs and waits there);
+        // both operands use the same load kind (with global_load next to buffer_load hipcc drained vmcnt(0)
+        // right after issuing the prefetch).  The chunk's channel offset rides in the scalar offset operand.
         const __amdgpu_buffer_rsrc_t xrsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
         unsigned xo[MAXX];   // byte offset of the slot's float4 (without the chunk's channel offset)
-        int xl[MAXX];        // LDS offset, -1 => slot unused
+        int xl[MAXX];        // float offset inside buffer 0 (or the sink)
+        int xd[MAXX];        // what to add for buffer 1 (0 for the sink)
 #pragma unroll
         for (int j = 0; j < MAXX; ++j) {
             const int idx = tid + 256 * j;
             xo[j] = 0x80000000u;
-            xl[j] = -1;
+            xl[j] = sink;
+            xd[j] = 0;
             if (idx < nrows * XQ) {
                 const int row = idx / XQ, q = idx - row * XQ;
-                const int seg = row / R, r = row - seg * R;
+                const int seg = (TB == 1) ? 0 : row / R, r = row - seg * R;
                 const int b = b0 + seg, tin = tin0 + r;
                 xl[j] = row * SX + 4 * q;
+                xd[j] = buf_floats;
                 if (b < p.B && tin >= 0 && tin < p.Tin)
                     xo[j] = (unsigned)(((long)b * p.xbs + (long)tin * p.Cin + 4 * q) * 4);
             }
         }
-        long wg[NW4];
-        int wl[NW4];     // LDS offset of the slot's first element inside the weight slab
-        int wk[NW4];     // CNK layout: tap index of that element (the 4 elements walk (n, k) in k-major order)
+        // weight units.  A flipped correlation (stride-1 dgrad) is flipped HERE, in the tap plane a value is
+        // stored to, so the operand reads of the loop keep compile-time offsets.
+        constexpr int NU = NCK ? UN : UC;
+        constexpr int NP = NCK ? K : 4;      // 16-B stores (= loads) per unit
+        unsigned wg[NU];     // byte offset of the unit's first float4 (without the chunk term)
+        int wl[NU];          // NCK: float offset of the unit's tap-plane-0 store inside buffer 0
+        int wd[NU][4];       // CNK: float offset of each of the unit's 4 stores inside buffer 0 (or the sink)
+        int wdd[NU];         // CNK: what to add for buffer 1 (0 for an idle unit)
+        const int wstep = p.flip ? -WT : WT;
 #pragma unroll
-        for (int j = 0; j < NW4; ++j) {
-            const int e4 = tid + 256 * j;
-            wk[j] = 0;
-            if (w_nck) {
-                constexpr int PER = BKC * K / 4;
-                const int n = e4 / PER, q = e4 - n * PER;
-                wg[j] = (long)(n0 + n) * p.w_sn + 4 * q;     // + c0*K per chunk
-                wl[j] = (4 * q) * SW + n;
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + 256 * i;
+            wl[i] = 0;
+            wdd[i] = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wd[i][e] = sink;
+            if constexpr (NCK) {
+                // 8 consecutive lanes = 8 consecutive columns (one conflict-free 128-B store group), then the quads
+                const int n = (u & 7) + 8 * ((u >> 3) / CG), cg = (u >> 3) % CG;
+                wg[i] = (unsigned)(((long)(n0 + n) * p.w_sn + (long)4 * cg * K) * 4);       // + c0*K per chunk
+                wl[i] = xs_floats + (p.flip ? (K - 1) * WT : 0) + (cg * BN + n) * 4;          // + k*wstep per tap
             } else {
-                constexpr int PER = BN * K / 4;
-                const int c = e4 / PER, q = e4 - c * PER;
-                const int n = (4 * q) / K, k = 4 * q - n * K;
-                wg[j] = (long)c * p.w_sc + (long)n0 * K + 4 * q;   // + c0*w_sc per chunk
-                wl[j] = (c * K + k) * SW + n;
-                wk[j] = k;
+                const int cg = u / P4, q = u - cg * P4;                   // lanes walk the contiguous (n,k) run
+                wg[i] = (unsigned)(((long)4 * cg * p.w_sc + (long)n0 * K + 4 * q) * 4);     // + c0*w_sc per chunk
+                if (cg < CG) {
+                    wdd[i] = buf_floats;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = (4 * q + e) / K, k = 4 * q + e - n * K;
+                        wd[i][e] = xs_floats + (p.flip ? K - 1 - k : k) * WT + (cg * BN + n) * 4;
+                    }
+                } else {
+                    wg[i] = (unsigned)((long)n0 * K * 4);                 // idle unit: any valid address
+                }
             }
         }
-        float4 xr[MAXX], wr[NW4];
-        auto load_x = [&](int j, int c0) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo[j] + 4u * (unsigned)c0, 0, 0);
-            xr[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        f32x4 xr[MAXX], wr[NU * NP];
+        auto bload = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned soff) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+            return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
         };
-        auto load_w = [&](int j, long woff) { wr[j] = *reinterpret_cast<const float4*>(p.w + wg[j] + woff); };
-        auto w_off = [&](int c0) { return w_nck ? (long)c0 * K : (long)c0 * p.w_sc; };
-        auto store_x = [&](int j, float* d) {
-            d[0] = xr[j].x; d[1] = xr[j].y; d[2] = xr[j].z; d[3] = xr[j].w;
+        auto x_soff = [&](int c0) { return 4u * (unsigned)c0; };
+        auto w_soff = [&](int c0) { return (unsigned)((NCK ? (long)c0 * K : (long)c0 * p.w_sc) * 4); };
+        auto load_x = [&](int j, unsigned soff) { xr[j] = bload(xrsrc, xo[j], soff); };
+        auto load_w = [&](int i, int part, unsigned soff) {
+            const unsigned step = NCK ? 16u : (unsigned)p.w_sc * 4u;      // next float4 of the run / next channel row
+            wr[i * NP + part] = bload(wrsrc, wg[i] + (unsigned)part * step, soff);
         };
-        // the 4 elements of a weight float4 walk k within a column (NCK: next LDS row each time) or (n, k) pairs
-        // in k-major order (CNK: next row until the tap wraps, then the next column); one branch-free form
-        const int wrapk = w_nck ? -1 : K - 1;
-        auto store_w = [&](int j, float* Wb) {
-            const float v[4] = {wr[j].x, wr[j].y, wr[j].z, wr[j].w};
-            int d = wl[j], k = wk[j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Wb[d] = v[i];
-                const bool wrap = (k == wrapk);
-                d += wrap ? 1 - (K - 1) * SW : SW;
-                k = wrap ? 0 : k + 1;
-            }
+        auto store_x = [&](int j, int buf) { *lds4(xl[j] + (buf ? xd[j] : 0)) = xr[j]; };
+        // one 16-B store of weight unit i: NCK part = tap k (element cc*K + k of the unit's 4K floats, cc = channel
+        // in the quad); CNK part = element e of the float4, i.e. (n, k) pair number 4q+e, from the 4 channel rows
+        // The 4 values of one 16-B weight quad come from 4 different prefetch registers (a register transpose).
+        // They are stored as two pairs (ds_write2_b32 takes two unrelated data registers): a ds_write in an MFMA
+        // gap is free, while the v_movs that would gather them for one ds_write_b128 are not -- a VALU instruction
+        // behind an MFMA delays the next MFMA by ~17 cycles (scratch/mfma_rate3.hip: 64.4 -> 82 cycles per MFMA
+        // with one v_mov per gap; one LDS/VMEM/SALU filler per gap: 64-69).  This file is built with
+        // -fno-slp-vectorize so that hipcc does not re-vectorise the pairs through v_movs.
+        auto store_pair = [&](int off, float v0, float v1) {     // floats off and off+2: NOT adjacent, or hipcc
+            float* d = smem + off;                               // merges the pair into v_movs + ds_write_b64
+            d[0] = v0; d[2] = v1;
+        };
+        auto wq = [&](int i, int part, int cc) -> float {      // value of channel cc of weight quad `part` of unit i
+            if constexpr (NCK) return wr[i * K + (cc * K + part) / 4][(cc * K + part) % 4];
+            else return wr[i * 4 + cc][part];
+        };
+        auto store_w = [&](int i, int part, int half, int buf) {
+            int off;
+            if constexpr (NCK) off = wl[i] + part * wstep + (buf ? buf_floats : 0);
+            else off = wd[i][part] + (buf ? wdd[i] : 0);
+            store_pair(off + half, wq(i, part, half), wq(i, part, half + 2));
         };
         auto load_chunk = [&](int c0) {
 #pragma unroll
-            for (int j = 0; j < MAXX; ++j) load_x(j, c0);
-            const long woff = w_off(c0);
+            for (int j = 0; j < MAXX; ++j) load_x(j, x_soff(c0));
 #pragma unroll
-            for (int j = 0; j < NW4; ++j) load_w(j, woff);
+            for (int i = 0; i < NU; ++i)
+#pragma unroll
+                for (int part = 0; part < NP; ++part) load_w(i, part, w_soff(c0));
         };
-        auto store_chunk = [&](int boff) {
+        // Gap-scheduled loop over two LDS buffers.  A chunk is NSLOT slots of 4 MFMAs (one tap x one channel
+        // group).  A wave issues in order and each MFMA waits 64 cycles for its predecessor on the same
+        // accumulator, so work hides under the matrix pipe only if it sits in the GAP right behind an MFMA in
+        // program order, a few instructions per gap (measured with -DMG_STAMPS: staging placed after a chunk's
+        // MFMAs, or clumped behind a slot's first MFMA, ran unoverlapped: 1.3 / 1.06 us per chunk against
+        // 0.70 us of MFMA time).  Gap 0 of a slot holds the operand reads of the NEXT slot (other register
+        // set); gaps 1-3 each hold at most a piece of the next chunk's round trip: prefetched registers ->
+        // other LDS buffer (one 16-B store), registers reloaded with the chunk after that (one 16-B load).
+        // sched_barrier pins every gap.  One barrier per chunk, in gap 0 of the last slot.  No branches: past
+        // the end the last chunk is re-staged into the idle buffer; slots without data write to the sink.
+        constexpr int NQ = TR2 ? 5 : K;             // MFMA quads per channel group
+        constexpr int NSLOT = G8 * NQ;
+        constexpr int NGAP = (NSLOT - 1) * 3;
+        // staging ops, one memory instruction each.  X slot j: store, then (next op, so not in the same gap: a load
+        // that overwrites the registers a store in front of it still reads costs ~20 cycles) its reload.  Weight
+        // unit i: 2*NP pair stores, then its NP reloads.
+        constexpr int NOPS = 2 * MAXX + NU * 3 * NP;
+        static_assert(NSLOT % 2 == 0, "operand register sets alternate per slot");
+        f32x4 fa[2][TM], fb[2][TN];
+        auto frag_read = [&](int boff, int slot, f32x4 (&A)[TM], f32x4 (&Bv)[TN]) {
+            const int g = slot / NQ, q = slot - g * NQ;
+            const int row = TR2 ? (q < 2 ? 2 : (q < 4 ? 1 : 0)) : q;
 #pragma unroll
-            for (int j = 0; j < MAXX; ++j)
-                if (xl[j] >= 0) store_x(j, Xs + boff + xl[j]);
+            for (int mi = 0; mi < TM; ++mi) A[mi] = *lds4(boff + abase[mi] + row * SX + 8 * g);
 #pragma unroll
-            for (int j = 0; j < NW4; ++j) store_w(j, Ws + boff);
+            for (int ni = 0; ni < TN; ++ni) Bv[ni] = *lds4(boff + bbase[ni] + q * WT + 2 * g * BN * 4);
+        };
+        const int c_last = c_end - BKC;
+        auto chunk = [&](auto parity, int c0) {
+            constexpr int P = decltype(parity)::value;      // buffer being read; the other one is being filled
+            const int cur = P ? buf_floats : 0, oth = buf_floats - cur;
+#ifdef MG_EXP_SAMECHUNK
+            const int cn = c_begin;
+#else
+            const int cn = min(c0 + 2 * BKC, c_last);
+#endif
+            const unsigned xs = x_soff(cn), ws = w_soff(cn);
+#pragma unroll
+            for (int m = 0; m < NSLOT * 4; ++m) {
+                const int sl = m / 4, s4 = m % 4;
+                const int ph = TR2 ? ((sl % NQ) & 1) : 0;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+                        acc[ph][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl & 1][mi][s4], fb[sl & 1][ni][s4],
+                                                                               acc[ph][mi][ni], 0, 0, 0);
+                if (s4 == 0) {
+#ifndef MG_EXP_NOBARRIER
+                    if (sl == NSLOT - 1) __syncthreads();      // the other buffer is complete, this one is read out
+#endif
+                    if (sl + 1 < NSLOT) frag_read(cur, sl + 1, fa[(sl + 1) & 1], fb[(sl + 1) & 1]);
+                    else frag_read(oth, 0, fa[0], fb[0]);
+                } else if (sl < NSLOT - 1) {
+                    const int gap = sl * 3 + s4 - 1;
+#pragma unroll
+                    for (int o = 0; o < NOPS; ++o) {
+                        if (o * NGAP / NOPS != gap) continue;
+                        if (o < 2 * MAXX) {
+#ifndef MG_EXP_NOXSTORE
+                            if (o % 2 == 0) store_x(o / 2, 1 - P);
+#endif
+#ifndef MG_EXP_NOLOADS
+                            if (o % 2 == 1) load_x(o / 2, xs);
+#endif
+                        } else {
+                            const int i = (o - 2 * MAXX) / (3 * NP), r = (o - 2 * MAXX) % (3 * NP);
+#ifndef MG_EXP_NOWSTORE
+                            if (r < 2 * NP) store_w(i, r / 2, r % 2, 1 - P);
+#endif
+#ifndef MG_EXP_NOLOADS
+                            if (r >= 2 * NP) load_w(i, r - 2 * NP, ws);
+#endif
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         load_chunk(c_begin);
         MG_STAMP(1);
-        store_chunk(0);
-        if (p.dbuf) {
-            // Software-pipelined loop over two LDS buffers.  The next chunk's round trip (prefetched registers ->
-            // other LDS buffer -> reload the registers with the chunk after it) is cut into per-slot pieces that
-            // sit BETWEEN the MFMA steps of the current chunk: a wave issues in order and every MFMA waits for
-            // its predecessor (same accumulator), so staging placed after the chunk's MFMAs ran unoverlapped
-            // (1.28 us per chunk against 0.64 us of MFMA time, measured with -DMG_STAMPS); placed between them
-            // it rides in their shadow.  The body has no branches: past the end the last chunk is re-staged
-            // into the idle buffer, and slots without a row write to a per-thread dummy.
-            constexpr int NSTEP = BKC / 2;
-            const int c_last = c_end - BKC;
-            const int dummy = 2 * buf_floats + 4 * tid;
-            load_chunk(min(c_begin + BKC, c_last));
-            __syncthreads();
-            MG_STAMP(2);
-            int cur = 0;
-            for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
-                const int oth = buf_floats - cur;
-                const int cn = min(c0 + 2 * BKC, c_last);
-                const long wn_off = w_off(cn);
-                const float* Xb = Xs + cur;
-                const float* Wb = Ws + cur;
-                auto pieces = [&](int c2) {
-#ifndef MG_EXP_NOPIECES
 #pragma unroll
-                    for (int j = 0; j < MAXX; ++j)
-                        if (j % NSTEP == c2) {
-                            store_x(j, smem + (xl[j] >= 0 ? oth + xl[j] : dummy));
-#ifndef MG_EXP_NOLOADS
-                            load_x(j, cn);
-#endif
-                        }
+        for (int j = 0; j < MAXX; ++j) store_x(j, 0);
 #pragma unroll
-                    for (int j = 0; j < NW4; ++j)
-                        if ((MAXX + j) % NSTEP == c2) {
-                            store_w(j, Ws + oth);
-#ifndef MG_EXP_NOLOADS
-                            load_w(j, wn_off);
-#endif
-                        }
-#endif
-                };
-                if constexpr (FRAG_DB) {
-                    float a0[NR][TM], b0[K][TN], a1[NR][TM], b1[K][TN];
-                    frag_load(Xb, Wb, 0, a0, b0);
+        for (int i = 0; i < NU; ++i)
 #pragma unroll
-                    for (int c2 = 0; c2 < NSTEP; c2 += 2) {
-                        frag_load(Xb, Wb, c2 + 1, a1, b1);
-                        frag_mma(a0, b0);
-                        pieces(c2);
-                        if (c2 + 2 < NSTEP) frag_load(Xb, Wb, c2 + 2, a0, b0);
-                        frag_mma(a1, b1);
-                        pieces(c2 + 1);
-                    }
-                } else {
-#pragma unroll
-                    for (int c2 = 0; c2 < NSTEP; ++c2) {
-                        float a0[NR][TM], b0[K][TN];
-                        frag_load(Xb, Wb, c2, a0, b0);
-                        frag_mma(a0, b0);
-                        pieces(c2);
-                    }
-                }
-                __syncthreads();
-                cur = oth;
-#ifdef MG_STAMPS
-                { const int it = (c0 - c_begin) / BKC; if (it < 2) MG_STAMP(8 + 4 * it); else if (it < 4) MG_STAMP(11 + it); }
-#endif
+            for (int part = 0; part < NP; ++part) {
+                store_w(i, part, 0, 0);
+                store_w(i, part, 1, 0);
             }
-        } else {
-            __syncthreads();
-            MG_STAMP(2);
-            for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
-                const bool more = c0 + BKC < c_end;
-#ifdef MG_STAMPS
-                const int it = (c0 - c_begin) / BKC;
-#endif
-                if (more) load_chunk(c0 + BKC);
-                compute(BKC / 2, 0);
-#ifdef MG_STAMPS
-                if (it < 2) MG_STAMP(5 + 4 * it);
-#endif
-                __syncthreads();
-#ifdef MG_STAMPS
-                if (it < 2) MG_STAMP(6 + 4 * it);
-#endif
-                if (more) {
-                    store_chunk(0);
-#ifdef MG_STAMPS
-                    if (it < 2) MG_STAMP(7 + 4 * it);
-#endif
-                    __syncthreads();
-                }
-#ifdef MG_STAMPS
-                if (it < 2) MG_STAMP(8 + 4 * it); else if (it < 4) MG_STAMP(11 + it);
-#endif
-            }
+        load_chunk(min(c_begin + BKC, c_last));
+        __syncthreads();
+        MG_STAMP(2);
+        frag_read(0, 0, fa[0], fb[0]);
+        for (int c0 = c_begin;;) {
+            chunk(std::integral_constant<int, 0>{}, c0);
+            c0 += BKC;
+            if (c0 >= c_end) break;
+            chunk(std::integral_constant<int, 1>{}, c0);
+            c0 += BKC;
+            if (c0 >= c_end) break;
         }
     } else {
-    for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
-        __syncthreads();
-        // ---- stage the input window chunk: rows (seg, r) x BKC channels ----
-        if (vec_ok) {
-            for (int idx = tid; idx < nrows * XQ; idx += 256) {
-                const int row = idx / XQ, q = idx - row * XQ;
-                const int seg = row / R, r = row - seg * R;
-                const int b = b0 + seg, tin = tin0 + r, c = c0 + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
-                    v = *reinterpret_cast<const float4*>(p.x + (long)b * p.xbs + (long)tin * p.Cin + c);
-                float* d = Xs + row * SX + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-        } else {
+        // generic path (ragged channel counts / unaligned tensors): scalar staging into the same LDS images
+        for (int c0 = c_begin; c0 < c_end; c0 += BKC) {
+            __syncthreads();
             for (int idx = tid; idx < nrows * BKC; idx += 256) {
                 const int row = idx / BKC, cl = idx - row * BKC;
                 const int seg = row / R, r = row - seg * R;
                 const int b = b0 + seg, tin = tin0 + r, c = c0 + cl;
                 float v = 0.f;
-                if (b < p.B && tin >= 0 && tin < p.Tin && c < p.Cin)
+                if (b < p.B && tin >= 0 && tin < p.Tin && c < c_end)
                     v = p.x[(long)b * p.xbs + (long)tin * p.Cin + c];
-                Xs[row * SX + cl] = v;
+                smem[row * SX + cl] = v;
             }
-        }
-        // ---- stage the weight slab: [(c_local, k)][n] ----
-        if (w_nck) {
             for (int e = tid; e < BN * BKC * K; e += 256) {
-                const int n = e / (BKC * K), ck = e - n * (BKC * K);
-                const int c = ck / K, k = ck - c * K;
+                int n, c, k;
+                if (NCK) {
+                    n = e / (BKC * K);
+                    const int ck = e - n * (BKC * K);
+                    c = ck / K; k = ck - c * K;
+                } else {
+                    c = e / (BN * K);
+                    const int nk = e - c * (BN * K);
+                    n = nk / K; k = nk - n * K;
+                }
                 float v = 0.f;
-                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
-                Ws[ck * SW + n] = v;
+                if (n0 + n < p.N && c0 + c < c_end) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
+                smem[xs_floats + (p.flip ? K - 1 - k : k) * WT + ((c >> 2) * BN + n) * 4 + (c & 3)] = v;
             }
-        } else {
-            for (int e = tid; e < BN * BKC * K; e += 256) {
-                const int c = e / (BN * K), nk = e - c * (BN * K);
-                const int n = nk / K, k = nk - n * K;
-                float v = 0.f;
-                if (n0 + n < p.N && c0 + c < p.Cin) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
-                Ws[(c * K + k) * SW + n] = v;
-            }
+            __syncthreads();
+            const int ng = min(G8, (c_end - c0 + 7) >> 3);
+            for (int g = 0; g < ng; ++g) group_mma(0, g);
         }
-        __syncthreads();
-        const int crem = c_end - c0;
-        compute((crem >= BKC ? BKC : crem + 1) >> 1, 0);
-    }
     }
 
     // ---- epilogue ----
@@ -530,6 +539,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         }
     }
     MG_STAMP(4);
+#ifdef MG_STAMPS
+    if (threadIdx.x == 0 && mg_stamp_buf)    // shader-clock cycles over the workgroup's life: slot 15
+    {
+        long long* sb = mg_stamp_buf + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
+        sb[15] = clock64() - clk0;
+        // slot 14: HW_ID (wave/simd/cu/sh/se) | XCC_ID << 32 -- which CU this workgroup ran on
+        sb[14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+#endif
 }
 
 // sums the split-K slabs in fixed order and applies the fused epilogue
@@ -550,8 +568,8 @@ __global__ void conv_finish_kernel(const float* __restrict__ part, float* __rest
 template <int S, int K, bool TR2, int TM, int TN>
 int launch_cfg(const ConvP& p0, hipStream_t stream) {
     ConvP p = p0;
-    constexpr int BM = 64 * TM, BN = 64 * TN, SW = BN + 1;
-    constexpr int BKC = ChunkOf<K>::value, SX = BKC + 1;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BKC = ChunkOf<K>::value, SX = BKC + 4;
     constexpr int SA = TR2 ? 1 : S;
     constexpr int NR = TR2 ? 3 : K;
     int lg = mg_ilog2_ceil(p.Tm);
@@ -561,25 +579,23 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     const int TT = 1 << lg, TB = BM >> lg;
     p.n_ttiles = (int)mg_cdiv(p.Tm, TT);
     const int R = (TT - 1) * SA + NR;
-    const size_t lds1 = ((size_t)((TB * R * SX + 3) & ~3) + (size_t)BKC * K * SW) * sizeof(float);
-    // single LDS buffer by default: twice the resident workgroups beat saving one barrier per chunk in every
-    // shape measured (e.g. 94.9 vs 85.6 TFLOP/s on the ED conv3 shape); MG_FORCE_DBUF=1 re-enables the double buffer
-    p.dbuf = 0;
-    if (const char* f = getenv("MG_FORCE_DBUF")) p.dbuf = atoi(f) ? 1 : 0;
-    const size_t lds = p.dbuf ? 2 * lds1 + 256 * 4 * sizeof(float) : lds1;
+    const size_t lds1 = ((size_t)TB * R * SX + (size_t)K * BKC * BN) * sizeof(float);
+    const size_t lds = 2 * lds1 + 256 * 4 * sizeof(float);   // two buffers + the per-thread staging sink
     if (lds > 160 * 1024) {
         mg_set_error("conv_wgemm: LDS request %zu too large", lds);
         return MG_EUNSUP;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgemm_kernel<S, K, TR2, TM, TN>),
+    const bool nck = p.w_sc < p.w_sn;   // (c,k) contiguous for a fixed n
+    auto kernel = nck ? &conv_wgemm_kernel<S, K, TR2, true, TM, TN> : &conv_wgemm_kernel<S, K, TR2, false, TM, TN>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[nck]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             mg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
             return MG_EHIP;
         }
-        attr_set = true;
+        attr_set[nck] = true;
     }
     dim3 grid((unsigned)(p.n_ttiles * mg_cdiv(p.B, TB)), (unsigned)mg_cdiv(p.N, BN));
     // split-K over workgroups when the output tiling alone leaves most of the 256 CUs idle
@@ -601,7 +617,7 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
             grid.z = (unsigned)p.ksplit;
         }
     }
-    hipLaunchKernelGGL((conv_wgemm_kernel<S, K, TR2, TM, TN>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
     MG_CHECK_LAUNCH("conv_wgemm");
     if (p.ksplit > 1) {
         hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)mg_cdiv(total, 256)), dim3(256), 0, stream,
@@ -681,6 +697,8 @@ extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B,
     p.w_sn = w_sn; p.w_sc = w_sc; p.flip = flip;
     p.work = work; p.work_bytes = work_bytes;
     { const long xb = ((long)(B - 1) * p.xbs + (long)Tin * Cin) * 4; p.x_bytes = xb < (1L << 31) ? xb : 0; }
+    { const long wb = ((long)(p.N - 1) * p.w_sn + (long)(p.Cin - 1) * p.w_sc + (p.w_sn < p.w_sc ? p.w_sn : p.w_sc)) * 4;
+      p.w_bytes = wb < (1L << 31) ? wb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (stride == 1) {
@@ -707,6 +725,8 @@ extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int 
     p.w_sn = w_sn; p.w_sc = w_sc; p.flip = 0;
     p.work = work; p.work_bytes = work_bytes;
     { const long xb = ((long)(B - 1) * p.xbs + (long)Tin * Cin) * 4; p.x_bytes = xb < (1L << 31) ? xb : 0; }
+    { const long wb = ((long)(p.N - 1) * p.w_sn + (long)(p.Cin - 1) * p.w_sc + (p.w_sn < p.w_sc ? p.w_sn : p.w_sc)) * 4;
+      p.w_bytes = wb < (1L << 31) ? wb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (scatter_tile((long)B * Tin, N) == 12) return launch_cfg<2, 5, true, 1, 2>(p, s);

@@ -159,7 +159,12 @@ def test_steps_match_oracle_and_golden(engine_mod, name):
         for k, gr in rg["grads"].items():
             if k in NOISE_PARAMS_G:
                 continue
-            ok, errs = grad_ok(eng.GE.g[k], gr, rg64["grads"][k], slack=6.0)
+            # floor 3e-3: in gan_c128_t64_b4 one ReLU/LeakyReLU mask decision sits within fp32 rounding of zero, and
+            # every generator gradient moves by 2.0e-3 (relative L2) when it flips.  The reference's OWN fp32 result
+            # flips with nothing but its CPU thread count: e_ref = 2.0e-3 with 128 threads, 2.9e-6 with 1 (measured;
+            # collecting the CPU test modules sets 1 thread), while ours is 2.0e-3 -- so "slack x e_ref" alone made
+            # this test depend on which other test files were collected.
+            ok, errs = grad_ok(eng.GE.g[k], gr, rg64["grads"][k], slack=6.0, floor=3e-3)
             assert ok, (it, k, errs)
         ge_old = eng.GE.data.clone()
         eng.g_update()
