@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int RED_SPLITS = 64;   // max row slices for two-stage column reductions
+constexpr int RED_SPLITS = 256;  // max row slices for two-stage column reductions
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 struct RedPlan { int nsplit; long rows_per; };
 RedPlan red_plan(long R) {
     RedPlan p;
-    long ns = mg_cdiv(R, 256);
+    long ns = mg_cdiv(R, 64);      // 64-row slices: even a 2-MB activation spreads over >= 128 workgroups
     if (ns > RED_SPLITS) ns = RED_SPLITS;
     if (ns < 1) ns = 1;
     p.rows_per = mg_cdiv(R, ns);
@@ -220,19 +220,37 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* _
 }
 
 // ---------------- mean over time ----------------
-__global__ void meanT_fwd_kernel(const float* __restrict__ a, float* __restrict__ h, int T, int C) {
+// block = 64 channels of one batch row: 16 float4 lanes x 16 time lanes (scalar fallback for ragged C)
+__global__ __launch_bounds__(256) void meanT_fwd_kernel(const float* __restrict__ a, float* __restrict__ h, int T, int C) {
     const int b = blockIdx.y;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ry = threadIdx.x >> 6;
-    __shared__ float sh[4][64];
-    float s = 0.f;
-    if (c < C)
-        for (int t = ry; t < T; t += 4) s += a[((long)b * T + t) * C + c];
-    sh[ry][threadIdx.x & 63] = s;
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 64 + 4 * cq;
+    __shared__ float sh[16][65];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = ((C & 3) == 0) && ((((uintptr_t)a) & 15) == 0);
+    if (c0 < C) {
+        for (int t = ry; t < T; t += 16) {
+            const float* row = a + ((long)b * T + t) * C + c0;
+            if (vec) {
+                const float4 v = *reinterpret_cast<const float4*>(row);
+                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < C) s[e] += row[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[ry][4 * cq + e] = s[e];
     __syncthreads();
-    if (ry == 0 && c < C) {
-        const int cx = threadIdx.x & 63;
-        h[(long)b * C + c] = (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) / (float)T;
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int y = 0; y < 16; ++y) t += sh[y][threadIdx.x];
+            h[(long)b * C + c] = t / (float)T;
+        }
     }
 }
 
@@ -347,20 +365,44 @@ __global__ void gp_interp_kernel(const float* __restrict__ real, const float* __
     xhat[i] = a * real[i] + (1.f - a) * fake[i];
 }
 
+// One workgroup per sample.  The sample's slice stays in registers between the norm and the scaling pass when it
+// fits (n <= 1024 threads x 8 float4: the 128x256 roll is exactly that), so g is read once, with 16-byte loads.
 __global__ __launch_bounds__(1024) void gp_norm_kernel(const float* __restrict__ g, float* __restrict__ gbar,
                                                        float* norms, float coef, int B, long n) {
     __shared__ float sh[16];
     const int b = blockIdx.x;
     const float* gb = g + (long)b * n;
+    const bool vec = ((n & 3) == 0) && (n <= 1024L * 32) && ((((uintptr_t)g) & 15) == 0) &&
+                     (gbar == nullptr || (((uintptr_t)gbar) & 15) == 0);
+    float4 v[8];
     float s = 0.f;
-    for (long i = threadIdx.x; i < n; i += blockDim.x) s += gb[i] * gb[i];
+    if (vec) {
+        const long n4 = n >> 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long i = threadIdx.x + 1024L * j;
+            v[j] = i < n4 ? reinterpret_cast<const float4*>(gb)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+    } else {
+        for (long i = threadIdx.x; i < n; i += blockDim.x) s += gb[i] * gb[i];
+    }
     s = block_sum(s, sh);
     const float nrm = sqrtf(s);
     if (threadIdx.x == 0) norms[b] = nrm;
     if (gbar) {
         const float fac = nrm > 0.f ? coef * (2.f / (float)B) * (nrm - 1.f) / nrm : 0.f;
         float* ob = gbar + (long)b * n;
-        for (long i = threadIdx.x; i < n; i += blockDim.x) ob[i] = fac * gb[i];
+        if (vec) {
+            const long n4 = n >> 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long i = threadIdx.x + 1024L * j;
+                if (i < n4) reinterpret_cast<float4*>(ob)[i] = make_float4(fac * v[j].x, fac * v[j].y, fac * v[j].z, fac * v[j].w);
+            }
+        } else {
+            for (long i = threadIdx.x; i < n; i += blockDim.x) ob[i] = fac * gb[i];
+        }
     }
 }
 

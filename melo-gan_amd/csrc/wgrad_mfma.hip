@@ -23,7 +23,9 @@ struct WgradP {
     const float* s[2];
     const float* l[2];
     int nb[2];
-    float* part;
+    float* part;     // [nsplit][slab] partial slabs, or null: single slice, write out / bias_out directly
+    float* out;
+    float* bias_out;
     int Ts, Tl, A, Bc;
     int tt_log2, n_ttiles;
     int bps;        // batch groups per split
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     // ---- add the four waves' accumulators tap by tap through LDS and write this slice's partial slab ----
     __syncthreads();
     float* red = smem;                                   // [4][32][33] floats = 16.9 KB (fits: RT*BA + window >= 2K+..)
-    float* out = p.part + (long)split * p.slab;
+    float* out = p.part ? p.part + (long)split * p.slab : p.out;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
 #pragma unroll
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
                 float v = 0.f;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) v += red[tid + 32 * g];
-                out[p.wslab + ch] = v;
+                if (p.part) out[p.wslab + ch] = v;
+                else p.bias_out[ch] = v;
             }
         }
     }
@@ -312,14 +315,16 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     const Plan pl = make_plan(A, Bc, K, nb0, nb1, Ts);
     const long wslab = (long)A * Bc * K;
     const long slab = wslab + (bias_from == 1 ? A : bias_from == 2 ? Bc : 0);
-    if (!work || work_bytes < (size_t)pl.nsplit * slab * sizeof(float)) {
+    if (pl.nsplit > 1 && (!work || work_bytes < (size_t)pl.nsplit * slab * sizeof(float))) {
         mg_set_error("mg_wgrad: workspace too small (%zu < %zu)", work_bytes, (size_t)pl.nsplit * slab * sizeof(float));
         return MG_EWORK;
     }
     WgradP p{};
     p.s[0] = s0; p.l[0] = l0; p.nb[0] = nb0;
     p.s[1] = s1; p.l[1] = l1; p.nb[1] = nb1;
-    p.part = (float*)work;
+    p.part = pl.nsplit > 1 ? (float*)work : nullptr;     // one slice: no slabs, no reduce launch
+    p.out = out;
+    p.bias_out = bias_out;
     p.Ts = Ts; p.Tl = Tl; p.A = A; p.Bc = Bc;
     p.tt_log2 = pl.tt_log2; p.n_ttiles = pl.n_ttiles;
     p.bps = pl.bps; p.n_bgroups = pl.nbg0 + pl.nbg1; p.nbg0 = pl.nbg0;
@@ -348,8 +353,10 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     }
 #undef MG_WG
     MG_CHECK_LAUNCH("wgrad_kernel");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(slab, 64)), dim3(256), 0, st,
-                       (const float*)work, out, bias_out, slab, wslab, pl.nsplit);
-    MG_CHECK_LAUNCH("reduce_slabs_kernel");
+    if (pl.nsplit > 1) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(slab, 64)), dim3(256), 0, st,
+                           (const float*)work, out, bias_out, slab, wslab, pl.nsplit);
+        MG_CHECK_LAUNCH("reduce_slabs_kernel");
+    }
     return MG_OK;
 }
