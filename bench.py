@@ -30,7 +30,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 B_PER_GPU, T, C = 64, 256, 128
-DOMINANT = "conv_wgemm_kernel<1,3,false,1,1>"
+# the dominant kernel: stride-1 K=3 64x64-tile window GEMM, both weight-layout instantiations (forward / data-gradient)
+DOMINANT = ("conv_wgemm_kernel<1,3,false,true,1,1>", "conv_wgemm_kernel<1,3,false,false,1,1>")
+DOMINANT_NAME = "conv_wgemm_kernel<1,3,false,{true|false},1,1>"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
 # conv+linear FLOPs per sample of one (1D+1G) step at cfg2 as the reference executes it
 MFLOP_PER_SAMPLE = 889.6
@@ -280,7 +282,7 @@ def main():
         # ---- roofline leg: HIP events around every launch of the dominant kernel symbol ----
         roof = None
         if rank == 0:
-            hook = EventHook(ops, {DOMINANT})
+            hook = EventHook(ops, set(DOMINANT))
             ops.set_launch_hook(hook)
             for i in range(args.profile_steps):
                 eng.set_batch(*pool[i % len(pool)])
@@ -290,7 +292,8 @@ def main():
                 eng.g_update()
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
-            sm = hook.summary().get(DOMINANT)
+            parts = [v for k, v in hook.summary().items() if k in DOMINANT]
+            sm = {k: sum(p_[k] for p_ in parts) for k in ("launches", "flops", "ms")} if parts else None
             if sm:
                 # HBM bytes per launch of this kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
                 # WRITE_SIZE passes, gfx950 correction applied): measured offline, committed under profiles/
@@ -298,13 +301,13 @@ def main():
                 try:
                     with open(os.path.join(ROOT, "profiles", "r01_traffic_dominant_kernel.json")) as f:
                         tj = json.load(f)
-                    if tj.get("kernel") == DOMINANT:
+                    if tj.get("kernel") == DOMINANT_NAME:
                         traffic = round(tj["traffic_bytes_per_launch"])
                 except (OSError, ValueError, KeyError):
                     pass
                 achieved = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, kernel=DOMINANT,
+                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, kernel=DOMINANT_NAME,
                             launches=sm["launches"], avg_us=round(1e3 * sm["ms"] / sm["launches"], 2),
                             avg_gflop_per_launch=round(sm["flops"] / sm["launches"] / 1e9, 3))
         loss_d, adv, emo = eng.loss_d_out[0].item(), eng.adv.item(), eng.emo.item()

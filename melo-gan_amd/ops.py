@@ -116,8 +116,9 @@ def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_
     if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
     lib = L.load()
-    sym = lambda: "conv_wgemm_kernel<%d,%d,false,%s>" % (  # noqa: E731
-        stride, K, {22: "2,2", 12: "1,2", 11: "1,1"}[lib.mg_conv_tile_config(B * Tout, N, 0)])
+    sym = lambda: "conv_wgemm_kernel<%d,%d,false,%s,%s>" % (  # noqa: E731  (S, K, TR2, NCK weight layout, tile)
+        stride, K, "true" if w_sc < w_sn else "false",
+        {22: "2,2", 12: "1,2", 11: "1,1"}[lib.mg_conv_tile_config(B * Tout, N, 0)])
     work = _conv_work(lib, B, Tout, N, Cin, x.device)
     with _observe(sym, 2.0 * B * Tout * N * Cin * K):
         rc = lib.mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
@@ -144,7 +145,8 @@ def conv_scatter2(x: Tensor, w: Tensor, y: Tensor, N: int, w_sn: int, w_sc: int,
     if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
     lib = L.load()
-    sym = lambda: f"conv_wgemm_kernel<2,5,true,{'1,2' if lib.mg_conv_tile_config(B * Tin, N, 1) == 12 else '1,1'}>"  # noqa: E731
+    sym = lambda: "conv_wgemm_kernel<2,5,true,%s,%s>" % (  # noqa: E731
+        "true" if w_sc < w_sn else "false", "1,2" if lib.mg_conv_tile_config(B * Tin, N, 1) == 12 else "1,1")
     work = _conv_work(lib, B, Tout, N, Cin, x.device)
     with _observe(sym, 2.0 * B * Tin * N * Cin * 5):
         rc = lib.mg_conv1d_scatter2(_p(x), _p(w), _p(y), B, Tin, Cin, N, Tout, w_sn, w_sc, Tin * Cin, y.shape[1] * N,
