@@ -12,8 +12,9 @@ the gradient all-reduce (N>1) and both Adam updates.  value = N*B*K / max-over-r
 
 The same JSON line carries
   roofline     : the dominant kernel SYMBOL (stride-1 K=3 64x64-tile window-GEMM: ED conv1-3 forward and their
-                 data-gradients, 6 launches = 20.9 of the step's 56.9 GFLOP), algorithmic FLOPs / HIP-event
-                 time of exactly those launches, against the dense fp32-MFMA peak (157.3 TFLOP/s);
+                 data-gradients, 6 launches = 20.9 of the step's 56.9 GFLOP).  The launches are recorded during
+                 one step and replayed (same tensors, one hipGraph, HIP events on the launch stream): algorithmic
+                 FLOPs / that time, against the dense fp32-MFMA peak (157.3 TFLOP/s);
   cpu_baseline : the oracle (PyTorch-CPU fp32 restatement of the reference step) timed on this
                  host's cores on a bounded number of the same steps (rank 0, N=1 only).
 """
@@ -46,46 +47,52 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for the roofline leg")
+    ap.add_argument("--profile-steps", type=int, default=20,
+                    help="replays of the dominant kernel's launches (one step's worth each) for the roofline leg; 0 = skip")
     ap.add_argument("--workload", default="gan", choices=["gan", "ae", "gen1"],
                     help="gan: the headline cfg2 step (default); ae: BASELINE config 4 (VAE step, B=256, T=256, C=4); "
                          "gen1: BASELINE config 5 (batch-1 E_num->G generation latency)")
     return ap.parse_args()
 
 
-class EventHook:
-    """Brackets every launch of the selected kernel symbols with HIP events on the launch stream."""
+class RecordHook:
+    """Remembers every launch of the selected kernel symbols (symbol, FLOPs, a closure that re-issues it)."""
 
-    def __init__(self, ops, symbols=None):
-        self.ops, self.symbols, self.records = ops, symbols, []
+    def __init__(self, symbols):
+        self.symbols, self.records = set(symbols), []
 
-    def __call__(self, symbol, flops):
+    def __call__(self, symbol, flops, launch=None):
         hook = self
 
         class Ctx:
             def __enter__(self_c):
-                self_c.on = hook.symbols is None or symbol in hook.symbols
-                if self_c.on:
-                    self_c.e0, self_c.e1 = hook.ops.Event(), hook.ops.Event()
-                    self_c.e0.record()
                 return self_c
 
             def __exit__(self_c, *a):
-                if self_c.on:
-                    self_c.e1.record()
-                    hook.records.append((symbol, flops, self_c.e0, self_c.e1))
+                if symbol in hook.symbols and launch is not None:
+                    hook.records.append((symbol, flops, launch))
                 return False
         return Ctx()
 
-    def summary(self):
-        out = {}
-        for sym, fl, e0, e1 in self.records:
-            ms = e0.elapsed_ms(e1)
-            d = out.setdefault(sym, dict(launches=0, flops=0.0, ms=0.0))
-            d["launches"] += 1
-            d["flops"] += fl
-            d["ms"] += ms
-        return out
+
+def time_dominant(ops, records, reps):
+    """HIP-event time of `reps` replays of the recorded launches (same tensors, same order as in the step), issued
+    back to back from one hipGraph on the launch stream: per-launch duration without host launch gaps."""
+    g = ops.Graph()
+    g.begin()
+    for _ in range(reps):
+        for _, _, launch in records:
+            rc = launch()
+            if rc != 0:
+                raise RuntimeError(f"replayed launch failed: rc={rc}")
+    g.end()
+    g.launch()                                   # warm
+    e0, e1 = ops.Event(), ops.Event()
+    e0.record()
+    g.launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_ms(e1)
 
 
 def host_cores() -> int:
@@ -279,22 +286,23 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
 
-        # ---- roofline leg: HIP events around every launch of the dominant kernel symbol ----
+        # ---- roofline leg: the dominant kernel's launches of one step, recorded and replayed under HIP events ----
         roof = None
-        if rank == 0:
-            hook = EventHook(ops, set(DOMINANT))
+        if rank == 0 and args.profile_steps > 0:
+            hook = RecordHook(DOMINANT)
             ops.set_launch_hook(hook)
-            for i in range(args.profile_steps):
-                eng.set_batch(*pool[i % len(pool)])
-                eng.d_backward_rng()
-                eng.d_update()
-                eng.g_backward_rng()
-                eng.g_update()
+            eng.set_batch(*pool[0])
+            eng.d_backward_rng()
+            eng.d_update()
+            eng.g_backward_rng()
+            eng.g_update()
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
-            parts = [v for k, v in hook.summary().items() if k in DOMINANT]
-            sm = {k: sum(p_[k] for p_ in parts) for k in ("launches", "flops", "ms")} if parts else None
-            if sm:
+            if hook.records:
+                reps = args.profile_steps
+                ms = time_dominant(ops, hook.records, reps)
+                launches = reps * len(hook.records)
+                flops = reps * sum(r[1] for r in hook.records)
                 # HBM bytes per launch of this kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
                 # WRITE_SIZE passes, gfx950 correction applied): measured offline, committed under profiles/
                 traffic = None
@@ -305,11 +313,11 @@ def main():
                         traffic = round(tj["traffic_bytes_per_launch"])
                 except (OSError, ValueError, KeyError):
                     pass
-                achieved = sm["flops"] / (sm["ms"] * 1e-3) / 1e12
+                achieved = flops / (ms * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, kernel=DOMINANT_NAME,
-                            launches=sm["launches"], avg_us=round(1e3 * sm["ms"] / sm["launches"], 2),
-                            avg_gflop_per_launch=round(sm["flops"] / sm["launches"] / 1e9, 3))
+                            launches=launches, avg_us=round(1e3 * ms / launches, 2),
+                            avg_gflop_per_launch=round(flops / launches / 1e9, 3))
         loss_d, adv, emo = eng.loss_d_out[0].item(), eng.adv.item(), eng.emo.item()
 
     cpu = None

@@ -112,17 +112,18 @@ RedPlan red_plan(long R) {
     return p;
 }
 
-// Final stage of the two-stage reductions: 64 channels x 4 groups per block; group g sums partial
-// slices g, g+4, ... and the four group sums are combined through LDS (<= 8 dependent loads per
-// thread instead of one serial chain over all slices).
+// Final stage of the two-stage reductions: 16 channels x 16 groups per 256-thread block; group g sums partial
+// slices g, g+16, ... and the group sums are combined through LDS in a fixed order (<= 16 dependent loads per
+// thread even with RED_SPLITS slices, and 4x the blocks of a 64-channel split).
+constexpr int FIN_CH = 16;      // channels per block of the final kernels
 __device__ __forceinline__ bool reduce_partials(const double* __restrict__ part, int nsplit, int C, bool want2,
                                                 double& s1, double& s2, int& c_out) {
-    __shared__ double sh[2][4][64];
-    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double sh[2][16][FIN_CH];
+    const int cx = threadIdx.x & (FIN_CH - 1), g = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + cx;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int k = g; k < nsplit; k += 4) {
+        for (int k = g; k < nsplit; k += 16) {
             a += part[((long)k * 2) * C + c];
             if (want2) b += part[((long)k * 2 + 1) * C + c];
         }
@@ -131,8 +132,13 @@ __device__ __forceinline__ bool reduce_partials(const double* __restrict__ part,
     __syncthreads();
     c_out = c;
     if (g != 0 || c >= C) return false;
-    s1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
-    s2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int y = 0; y < 16; ++y) {
+        s1 += sh[0][y][cx];
+        s2 += sh[1][y][cx];
+    }
     return true;
 }
 
@@ -670,7 +676,7 @@ int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq, void* wor
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, x, nullptr, nullptr, nullptr, nullptr, 0, R, C,
                        pl.rows_per, (double*)work, sumsq ? 1 : 0);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(nblk(C, 64)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, sum, sumsq);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(nblk(C, FIN_CH)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, sum, sumsq);
     MG_CHECK_LAUNCH("colsum");
     return MG_OK;
 }
@@ -685,7 +691,7 @@ int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma,
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, z, nullptr, nullptr, nullptr, nullptr, 0, R, C,
                        pl.rows_per, (double*)work, 1);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C, 64)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, R,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C, FIN_CH)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, R,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, z, a, R * C, C, gamma, beta, save_mean,
                        save_invstd, act);
@@ -704,7 +710,7 @@ int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, 
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), 0, ST, da, a, z, save_mean, save_invstd, act, R, C,
                        pl.rows_per, part, 1);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C, 64)), dim3(256), 0, ST, (const double*)part, pl.nsplit, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C, FIN_CH)), dim3(256), 0, ST, (const double*)part, pl.nsplit, C, dgamma,
                        dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, da, a, z, dz, R * C, C, R, gamma,
                        save_mean, save_invstd, (const double*)sums, act);

@@ -72,6 +72,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
 
     // this wave's quarter of the chunk: rows [wave*16, wave*16+16)
     auto compute = [&]() {
+#ifdef MG_EXP_NOMMA
+        return;
+#endif
 #pragma unroll
         for (int r2 = 0; r2 < RT / 8; ++r2) {
             const int r = wave * (RT / 4) + 2 * r2 + h;
@@ -155,7 +158,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
             __syncthreads();
             for (int c = 0; c < n_chunks; ++c) {
                 const bool more = c + 1 < n_chunks;
+#ifndef MG_EXP_NOLOADS
                 if (more) load_chunk(c + 1);
+#endif
                 bias_accum((g_begin + c / p.n_ttiles) < p.nbg0 ? 0 : 1);
                 compute();
                 __syncthreads();
@@ -200,9 +205,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
         }
     }
 
-    // ---- add the four waves' accumulators tap by tap through LDS and write this slice's partial slab ----
+    // ---- add the four waves' accumulators tap by tap through LDS into the output tile ot[a][b*K + k] (the layout
+    //      of `out`), then write the tile's rows -- K*32 contiguous floats each -- with coalesced stores.  (Writing
+    //      each tap straight to out[(a*Bc + b)*K + k] scattered 4-byte stores 4*K bytes apart and cost 7-8 us per
+    //      launch.) ----
+#ifdef MG_EXP_NOEPI
+    if (acc[0][0] != 12345.f) return;
+#endif
     __syncthreads();
-    float* red = smem;                                   // [4][32][33] floats = 16.9 KB (fits: RT*BA + window >= 2K+..)
+    float* red = smem;                                   // [4][32][33]
+    float* ot = smem + 4 * 32 * 33;                      // [32][K*32 + 1]
+    constexpr int OTS = K * 32 + 1;
     float* out = p.part ? p.part + (long)split * p.slab : p.out;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -213,14 +226,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
         for (int q = 0; q < 4; ++q) {
             const int idx = tid + 256 * q;
             const int ar = idx >> 5, bc = idx & 31;
-            const int a = a0 + ar, b = b0 + bc;
-            if (a < p.A && b < p.Bc) {
-                const float v = (red[(0 * 32 + ar) * 33 + bc] + red[(1 * 32 + ar) * 33 + bc]) +
-                                (red[(2 * 32 + ar) * 33 + bc] + red[(3 * 32 + ar) * 33 + bc]);
-                out[((long)a * p.Bc + b) * K + k] = v;
-            }
+            ot[ar * OTS + bc * K + k] = (red[(0 * 32 + ar) * 33 + bc] + red[(1 * 32 + ar) * 33 + bc]) +
+                                        (red[(2 * 32 + ar) * 33 + bc] + red[(3 * 32 + ar) * 33 + bc]);
         }
         __syncthreads();
+    }
+    {
+        const int nb_valid = min(32, p.Bc - b0) * K;     // floats per row of this tile that exist in `out`
+        for (int idx = tid; idx < 32 * K * 32; idx += 256) {
+            const int ar = idx / (K * 32), j = idx - ar * (K * 32);
+            const int a = a0 + ar;
+            if (a < p.A && j < nb_valid) out[((long)a * p.Bc + b0) * K + j] = ot[ar * OTS + j];
+        }
     }
     if (do_bias_s || do_bias_l) {        // 8 row-lane partials -> one value per channel of this tile
         red[tid] = bsum;
@@ -335,7 +352,8 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     const int TT = 1 << pl.tt_log2;
     const int R = (TT - 1) * stride + K;
     size_t lds_floats = (size_t)RT * BA + (size_t)pl.TB * R * BB;
-    if (lds_floats < 4 * 32 * 33) lds_floats = 4 * 32 * 33;     // the final cross-wave reduction reuses the buffer
+    const size_t epi_floats = 4 * 32 * 33 + 32 * ((size_t)K * 32 + 1);     // the final cross-wave reduction reuses the buffer
+    if (lds_floats < epi_floats) lds_floats = epi_floats;
     const size_t lds = lds_floats * sizeof(float);
     {
         auto ok = [](const float* q, long elems) { return q == nullptr || (((((uintptr_t)q) & 15) == 0) && elems * 4 < (1L << 31)); };

@@ -72,10 +72,11 @@ class _NullCtx:
         return False
 
 
-def _observe(symbol_fn, flops):
+def _observe(symbol_fn, flops, launch=None):
+    """`launch` (optional) re-issues exactly this launch -- a profiling hook may keep it to replay the launch later."""
     if _launch_hook is None:
         return _NullCtx()
-    return _launch_hook(symbol_fn(), flops)
+    return _launch_hook(symbol_fn(), flops, launch)
 
 
 def _numel(shape):
@@ -120,10 +121,12 @@ def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_
         stride, K, "true" if w_sc < w_sn else "false",
         {22: "2,2", 12: "1,2", 11: "1,1"}[lib.mg_conv_tile_config(B * Tout, N, 0)])
     work = _conv_work(lib, B, Tout, N, Cin, x.device)
-    with _observe(sym, 2.0 * B * Tout * N * Cin * K):
-        rc = lib.mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
-                                  Tin * Cin, y.shape[1] * N, C.byref(e), _p(work), work.numel() if work is not None else 0,
-                                  _stream())
+    def launch():
+        return lib.mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
+                                    Tin * Cin, y.shape[1] * N, C.byref(e), _p(work),
+                                    work.numel() if work is not None else 0, _stream())
+    with _observe(sym, 2.0 * B * Tout * N * Cin * K, launch):
+        rc = launch()
     L.check(rc, "mg_conv1d_gather")
     return y
 

@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, melo_gan_amd
+from melo_gan_amd import _lib
+if os.environ.get("MELO_LIB_VARIANT"):      # a tools/build_variant.sh build
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libmelogan_" + os.environ["MELO_LIB_VARIANT"] + ".so")
 from melo_gan_amd import ops
 
 def timeit(fn, reps=20):
