@@ -16,6 +16,8 @@
 // conv.0: 8 tiles x 32 slices = 256 workgroups with 32 slabs instead of 2 x 64 = 128 with 64 slabs).
 // The bias gradient (column sums of S or of L) can ride along in the same launch.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -43,6 +45,19 @@ constexpr int BA = 32, BB = 32;   // output tile per workgroup
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// -DMG_STAMPS: debug build that records wall-clock stamps (100 MHz) of workgroup phases; see tools/
+#ifdef MG_STAMPS
+__device__ long long* mg_wstamp_buf = nullptr;
+#define MG_STAMP(k)                                                                                        \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && mg_wstamp_buf)                                                             \
+            mg_wstamp_buf[((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = \
+                wall_clock64();                                                                            \
+    } while (0)
+#else
+#define MG_STAMP(k)
+#endif
+
 template <int S, int K>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     constexpr int PAD = (K - 1) / 2;
@@ -51,6 +66,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     constexpr int NL4 = (RMAX * (BB / 4) + 255) / 256 + 1; // float4 prefetch slots for L
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    MG_STAMP(0);
     const int TT = 1 << p.tt_log2, TB = RT >> p.tt_log2;
     const int R = (TT - 1) * S + K;
     const int lrows = TB * R;
@@ -91,21 +107,172 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     float bsum = 0.f;
     const bool do_bias_s = p.bias_from == 1 && blockIdx.y == 0;
     const bool do_bias_l = p.bias_from == 2 && blockIdx.x == 0;
-    auto bias_accum = [&](int seg_id) {
+    auto bias_accum_at = [&](int boff, int seg_id) {
         if (seg_id >= p.nseg_bias) return;
         const int cx = tid & 31, rq = tid >> 5;      // 32 channels x 8 row lanes
         if (do_bias_s) {
 #pragma unroll
-            for (int r = rq; r < RT; r += 8) bsum += Ss[r * BA + cx];
+            for (int r = rq; r < RT; r += 8) bsum += Ss[boff + r * BA + cx];
         } else if (do_bias_l) {
             // each L row belongs to exactly one chunk: window rows [PAD, PAD + TT*S) of every segment
             for (int seg = 0; seg < TB; ++seg)
-                for (int rr = PAD + rq; rr < PAD + TT * S; rr += 8) bsum += Ls[(seg * R + rr) * BB + cx];
+                for (int rr = PAD + rq; rr < PAD + TT * S; rr += 8) bsum += Ls[boff + (seg * R + rr) * BB + cx];
         }
     };
 
+    auto bias_accum = [&](int seg_id) { bias_accum_at(0, seg_id); };
+
     const bool fast = ((p.A & 3) == 0) && ((p.Bc & 3) == 0) && p.vec_ok && (lrows * (BB / 4) <= 256 * NL4);
-    if (fast) {
+    if (fast && p.tt_log2 >= 4 && n_chunks > 0) {
+        // ---- gap-scheduled loop over two LDS buffers (same rules as conv_mfma.hip's: a wave issues in order, so
+        //      staging hides under the matrix pipe only as single LDS / VMEM instructions in the gaps between MFMAs;
+        //      VALU work costs ~17 cycles per gap and is done once per chunk, ahead of its MFMAs).  With
+        //      TT >= 16 a wave's 16 rows lie in one sequence, so every operand address is lane base + immediate. ----
+        constexpr int BUF = 0;   // (documentation only)
+        (void)BUF;
+        const int buf_floats = RT * BA + lrows * BB;
+        const int sink = 2 * buf_floats + 4 * tid;      // per-thread 16-B sink for L slots beyond the window
+        // prefetch slots: LDS float offset inside buffer 0 and chunk-invariant pieces of the global offset
+        int s_seg[NS4], s_tl[NS4], s_q[NS4];
+#pragma unroll
+        for (int j = 0; j < NS4; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / (BA / 4);
+            s_q[j] = idx - r * (BA / 4);
+            s_seg[j] = r >> p.tt_log2;
+            s_tl[j] = r & (TT - 1);
+        }
+        int l_seg[NL4], l_rr[NL4], l_q[NL4], l_lds[NL4], l_ldd[NL4];
+#pragma unroll
+        for (int j = 0; j < NL4; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (BB / 4);
+            l_q[j] = idx - row * (BB / 4);
+            l_seg[j] = (TB == 1) ? 0 : row / R;
+            l_rr[j] = row - l_seg[j] * R;
+            const bool live = row < lrows;
+            l_lds[j] = live ? RT * BA + 4 * idx : sink;
+            l_ldd[j] = live ? buf_floats : 0;
+            if (!live) l_seg[j] = 1 << 20;               // never a valid batch
+        }
+        f32x4 sr[NS4], lr[NL4];
+        unsigned so[NS4], lo[NL4];       // byte offsets of the chunk being fetched (0x80000000 = reads as zero)
+        __amdgpu_buffer_rsrc_t srs, lrs;
+        // chunk-invariant part of every slot's byte offset (batch 0, time 0 of the chunk's window); the chunk adds one
+        // wave-uniform term and three compares per slot -- the only VALU work per chunk
+        unsigned s_base[NS4], l_base[NL4];
+#pragma unroll
+        for (int j = 0; j < NS4; ++j) {
+            s_base[j] = (unsigned)((((long)s_seg[j] * p.Ts + s_tl[j]) * p.A + a0 + 4 * s_q[j]) * 4);
+            if (a0 + 4 * s_q[j] >= p.A) s_seg[j] = 1 << 20;          // never valid
+        }
+#pragma unroll
+        for (int j = 0; j < NL4; ++j) {
+            l_base[j] = (unsigned)((((long)l_seg[j] * p.Tl + l_rr[j]) * p.Bc + b0 + 4 * l_q[j]) * 4);
+            if (b0 + 4 * l_q[j] >= p.Bc) l_seg[j] = 1 << 20;
+        }
+        auto chunk_addr = [&](int c) {
+            const int g = g_begin + c / p.n_ttiles, tt = c - (c / p.n_ttiles) * p.n_ttiles;
+            const int seg_id = g < p.nbg0 ? 0 : 1;
+            const int bg = seg_id ? g - p.nbg0 : g;
+            const int nb = p.nb[seg_id];
+            const int bb0 = bg * TB, t0 = tt * TT, tl0 = t0 * S - PAD;
+            srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(seg_id ? p.s[1] : p.s[0]), 0,
+                                                    (int)((long)nb * p.Ts * p.A * 4), 0x00020000);
+            lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(seg_id ? p.l[1] : p.l[0]), 0,
+                                                    (int)((long)nb * p.Tl * p.Bc * 4), 0x00020000);
+            const unsigned s_add = (unsigned)((((long)bb0 * p.Ts + t0) * p.A) * 4);
+            const unsigned l_add = (unsigned)((((long)bb0 * p.Tl + tl0) * p.Bc) * 4);     // tl0 < 0 wraps; the sum is right
+            const int nbv = nb - bb0, tsv = p.Ts - t0;
+#pragma unroll
+            for (int j = 0; j < NS4; ++j)
+                so[j] = (s_seg[j] < nbv && s_tl[j] < tsv) ? s_base[j] + s_add : 0x80000000u;
+#pragma unroll
+            for (int j = 0; j < NL4; ++j) {
+                const int t = tl0 + l_rr[j];
+                lo[j] = (l_seg[j] < nbv && t >= 0 && t < p.Tl) ? l_base[j] + l_add : 0x80000000u;
+            }
+        };
+        auto bload = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned off) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        };
+        auto lds4 = [&](int off) { return reinterpret_cast<f32x4*>(__builtin_assume_aligned(smem + off, 16)); };
+        auto store_s = [&](int j, int buf) { *lds4(4 * (tid + 256 * j) + (buf ? buf_floats : 0)) = sr[j]; };
+        auto store_l = [&](int j, int buf) { *lds4(l_lds[j] + (buf ? l_ldd[j] : 0)) = lr[j]; };
+
+        // this lane's operand bases inside a buffer: rows wave*16 + 2*r2 + h of the chunk
+        const int r0 = wave * (RT / 4) + h;
+        const int abase = r0 * BA + (lane & 31);
+        const int lbase = RT * BA + ((r0 >> p.tt_log2) * R + (r0 & (TT - 1)) * S) * BB + (lane & 31);
+        constexpr int NR2 = RT / 8;                 // MFMA row-pairs per wave per chunk
+        constexpr int NOPS = 2 * (NS4 + NL4);       // store / reload of every prefetch slot
+        constexpr int NGAP = (NR2 - 1) * K;         // gaps ahead of the barrier
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        f32x8 fr[2];        // operand sets of two consecutive row pairs: [0..K-1] = the K taps of L, [7] = S
+        auto frag_read = [&](int boff, int r2) {
+            f32x8 v;
+            v[7] = smem[boff + abase + 2 * r2 * BA];
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[k] = smem[boff + lbase + (2 * r2 * S + k) * BB];
+            return v;
+        };
+        auto chunk = [&](auto parity, int c) {
+            constexpr int P = decltype(parity)::value;
+            const int cur = P ? buf_floats : 0, oth = buf_floats - cur;
+            bias_accum_at(cur, (g_begin + c / p.n_ttiles) < p.nbg0 ? 0 : 1);
+            chunk_addr(min(c + 2, n_chunks - 1));    // addresses of the chunk the reloads below fetch
+#pragma unroll
+            for (int m = 0; m < NR2 * K; ++m) {
+                const int r2 = m / K, k = m % K;
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[r2 & 1][7], fr[r2 & 1][k], acc[k], 0, 0, 0);
+                if (k == 0) {
+                    if (r2 == NR2 - 1) __syncthreads();           // other buffer complete, this one read out
+                    if (r2 + 1 < NR2) fr[(r2 + 1) & 1] = frag_read(cur, r2 + 1);
+                    else fr[0] = frag_read(oth, 0);
+                }
+                if (r2 < NR2 - 1) {
+                    const int gap = r2 * K + k;
+#pragma unroll
+                    for (int o = 0; o < NOPS; ++o) {
+                        if (o * NGAP / NOPS != gap) continue;
+                        const int j = o / 2;
+                        if (j < NS4) {
+                            if (o % 2 == 0) store_s(j, 1 - P);
+                            else sr[j] = bload(srs, so[j]);
+                        } else {
+                            if (o % 2 == 0) store_l(j - NS4, 1 - P);
+                            else lr[j - NS4] = bload(lrs, lo[j - NS4]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto load_all = [&]() {
+#pragma unroll
+            for (int j = 0; j < NS4; ++j) sr[j] = bload(srs, so[j]);
+#pragma unroll
+            for (int j = 0; j < NL4; ++j) lr[j] = bload(lrs, lo[j]);
+        };
+        chunk_addr(0);
+        load_all();
+#pragma unroll
+        for (int j = 0; j < NS4; ++j) store_s(j, 0);
+#pragma unroll
+        for (int j = 0; j < NL4; ++j) store_l(j, 0);
+        chunk_addr(min(1, n_chunks - 1));
+        load_all();
+        __syncthreads();
+        fr[0] = frag_read(0, 0);
+        MG_STAMP(1);
+        for (int c = 0;;) {
+            chunk(std::integral_constant<int, 0>{}, c);
+            if (++c >= n_chunks) break;
+            chunk(std::integral_constant<int, 1>{}, c);
+            if (++c >= n_chunks) break;
+        }
+    } else if (fast) {
         // the next chunk's S rows and L window are fetched with raw-buffer float4 loads (out-of-range slots
         // return 0 in hardware) while the current chunk is multiplied; single LDS buffer, two barriers per chunk
         float4 sr[NS4], lr[NL4];
@@ -212,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
 #ifdef MG_EXP_NOEPI
     if (acc[0][0] != 12345.f) return;
 #endif
+    MG_STAMP(2);
     __syncthreads();
     float* red = smem;                                   // [4][32][33]
     float* ot = smem + 4 * 32 * 33;                      // [32][K*32 + 1]
@@ -253,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
             }
         }
     }
+    MG_STAMP(3);
 }
 
 // out[i] = sum_z part[z][i]; 64 elements x 4 slice-groups per block (fixed summation order => reproducible).
@@ -292,8 +461,11 @@ Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
     pl.nbg1 = nb1 > 0 ? (int)mg_cdiv(nb1, pl.TB) : 0;
     const int ngroups = pl.nbg0 + pl.nbg1;
     const long tiles = mg_cdiv(A, BA) * mg_cdiv(Bc, BB);
-    // aim for ~768 workgroups (3 per CU), at least 2 r-chunks per split, at most MAX_SPLITS slabs
-    long want = mg_cdiv(768, tiles);
+    // aim for ~256 workgroups, at least 2 r-chunks per split, at most MAX_SPLITS slabs
+    long target = 256;      // one workgroup per CU: the gap-scheduled loop overlaps its own staging, and fewer slices
+                            // mean fewer prologues / cross-wave epilogues per CU and fewer slabs to reduce
+    if (const char* f = getenv("MG_WGRAD_TARGET")) target = atol(f);
+    long want = mg_cdiv(target, tiles);
     long max_by_work = ((long)ngroups * pl.n_ttiles) / 2;
     if (max_by_work < 1) max_by_work = 1;
     if (want > max_by_work) want = max_by_work;
@@ -306,6 +478,12 @@ Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
 }
 
 }  // namespace
+
+#ifdef MG_STAMPS
+extern "C" int mg_dbg_set_wstamps(long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(mg_wstamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t mg_wgrad_workspace_bytes(int A, int Bc, int K, int nb_total, int Ts) {
     // upper bound over any (nb0, nb1) split of nb_total: nsplit <= min(MAX_SPLITS, #batch groups);
@@ -351,7 +529,7 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     p.nseg_bias = 1;      // only segment 0 (the loss term) carries a bias gradient; the penalty segment has none
     const int TT = 1 << pl.tt_log2;
     const int R = (TT - 1) * stride + K;
-    size_t lds_floats = (size_t)RT * BA + (size_t)pl.TB * R * BB;
+    size_t lds_floats = 2 * ((size_t)RT * BA + (size_t)pl.TB * R * BB) + 256 * 4;   // two buffers + the staging sink
     const size_t epi_floats = 4 * 32 * 33 + 32 * ((size_t)K * 32 + 1);     // the final cross-wave reduction reuses the buffer
     if (lds_floats < epi_floats) lds_floats = epi_floats;
     const size_t lds = lds_floats * sizeof(float);
