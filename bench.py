@@ -252,17 +252,7 @@ def main():
 
     def step(i):
         eng.set_batch(*pool[i % len(pool)])
-        eng.run("d_backward_rng", use_graph)      # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
-        dp.allreduce_d()
-        eng.run("d_update", use_graph)
-        if world > 1:        # overlap the 16.8 MB pre.2 gradient all-reduce with the tail of backward
-            eng.run("g_backward_a_rng", use_graph)
-            dp.start_g_big()
-            eng.run("g_backward_b", use_graph)
-            dp.finish_g()
-        else:
-            eng.run("g_backward_rng", use_graph)
-        eng.run("g_update", use_graph)
+        dp.step(use_graph)        # melo-gan_amd/gan/dp.py: the graphs of one step and, for N > 1, the overlapped all-reduces
 
     def barrier():
         if world > 1:

@@ -60,6 +60,8 @@ class DataParallel:
                                                   group=self.group, async_op=True))
 
     def finish_g(self):
+        """All-reduces what start_g_big() left (one contiguous range: the engine places the big tensor first in the
+        flat buffer) and waits for the big slice."""
         if self.world == 1 or self.dist is None:
             return
         off, n = self.engine.big_grad_slice()
@@ -68,6 +70,43 @@ class DataParallel:
             self._allreduce(g[:off])
         if off + n < g.numel():
             self._allreduce(g[off + n:])
+        self._wait()
+
+    def _wait(self):
         for w in self._pending:
             w.wait()
         self._pending.clear()
+
+    # ---- the critic's gradient: latency-bound 1.25 MB, hidden behind the G-step's generator forward -------------
+    def start_d(self):
+        if self.world == 1 or self.dist is None:
+            return
+        self._pending.append(self.dist.all_reduce(self.engine.D.grad, op=self.dist.ReduceOp.SUM, group=self.group,
+                                                  async_op=True))
+
+    def step(self, use_graph: bool = True, g_step: bool = True):
+        """One training step (1 critic update, optionally 1 generator update) on the batch already set with
+        engine.set_batch().  world == 1: two graphs per sub-step.  world > 1: the critic's all-reduce overlaps the
+        generator forward of the G-step (which does not read the critic), decoder.pre.2.weight's all-reduce overlaps
+        the tail of backward, the rest of the generator gradient is one more all-reduce."""
+        e = self.engine
+        e.run("d_backward_rng", use_graph)          # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
+        if self.world == 1 or self.dist is None:
+            e.run("d_update", use_graph)
+            if g_step:
+                e.run("g_backward_rng", use_graph)
+                e.run("g_update", use_graph)
+            return
+        if not g_step:
+            self.allreduce_d()
+            e.run("d_update", use_graph)
+            return
+        self.start_d()
+        e.run("g_forward_rng", use_graph)
+        self._wait()
+        e.run("d_update", use_graph)
+        e.run("g_backward_a2", use_graph)
+        self.start_g_big()
+        e.run("g_backward_b", use_graph)
+        self.finish_g()
+        e.run("g_update", use_graph)

@@ -115,19 +115,23 @@ def emotion_disc_spec(cfg: dict):
 class FlatParams:
     """All tensors of one optimiser in a single flat fp32 buffer (+ grads, Adam m/v, step state)."""
 
-    def __init__(self, spec: "OrderedDict[str, tuple]", device, with_opt: bool = True):
+    def __init__(self, spec: "OrderedDict[str, tuple]", device, with_opt: bool = True, first: Optional[str] = None):
+        """`first`: tensor placed at offset 0 of the flat buffers (the dict order stays the spec's) -- the data-parallel
+        wrapper all-reduces that tensor's gradient early and everything behind it as ONE contiguous range."""
         self.spec = spec
         self.n = sum(math.prod(s) for s in spec.values())
         pad = (-self.n) % 4
         self.data = torch.zeros(self.n + pad, device=device)
         self.p: Dict[str, Tensor] = OrderedDict()
-        off = 0
         self.offsets = {}
-        for k, s in spec.items():
-            n = math.prod(s)
-            self.p[k] = self.data[off:off + n].view(s)
+        off = 0
+        for k in ([first] if first else []) + [k for k in spec if k != first]:
+            n = math.prod(spec[k])
             self.offsets[k] = (off, n)
             off += n
+        for k, s in spec.items():
+            o, n = self.offsets[k]
+            self.p[k] = self.data[o:o + n].view(s)
         self.g: Dict[str, Tensor] = OrderedDict()
         if with_opt:
             self.grad = torch.zeros_like(self.data)
@@ -180,7 +184,7 @@ class GanEngine:
         gspec = generator_spec(self.noise_dim, self.latent_dim, self.mode, 512, T, C, self.E)
         espec = feature_encoder_spec(self.num_in, self.enc_hidden, self.E)
         ge = OrderedDict([("G." + k, s) for k, s in gspec.items()] + [("E." + k, s) for k, s in espec.items()])
-        self.GE = FlatParams(ge, d)
+        self.GE = FlatParams(ge, d, first="G.decoder.pre.2.weight")
         self.D = FlatParams(discriminator_spec(C, 256, self.E), d)
         edspec, edbufs, self.ed_chans = emotion_disc_spec(self.ed_cfg)
         self.ED = FlatParams(edspec, d, with_opt=False)
@@ -554,15 +558,28 @@ class GanEngine:
         self.g_backward_a()
         self.g_backward_b()
 
-    def g_backward_a(self):
-        """G-step up to and including decoder.pre.2's weight gradient (89 % of the G+E_num gradient bytes): the
-        data-parallel wrapper starts that slice's all-reduce here and overlaps it with g_backward_b."""
-        B = self.B
-        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
+    def g_forward(self):
+        """E_num + generator forward of the G-step: independent of the critic, so under data parallelism it runs while
+        the critic's gradient all-reduce is in flight (DataParallel.step)."""
         if not self._ed_folded:
             self.fold_ed()
         self._e_fwd(train=True)
         self._g_fwd(self.notes, train=True)
+
+    def g_forward_rng(self):
+        self.draw_randoms(with_alpha=False)
+        self.g_forward()
+
+    def g_backward_a(self):
+        """G-step up to and including decoder.pre.2's weight gradient (89 % of the G+E_num gradient bytes): the
+        data-parallel wrapper starts that slice's all-reduce here and overlaps it with g_backward_b."""
+        self.g_forward()
+        self.g_backward_a2()
+
+    def g_backward_a2(self):
+        """g_backward_a without the generator forward (see g_forward)."""
+        B = self.B
+        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         # the critic branch (forward + input gradient) runs beside the emotion-discriminator branch
         with self._branch(0, critic=True):
             self._d_fwd(self.notes, B)

@@ -11,6 +11,11 @@ Differences that do not change results: the epoch's batches come from an HBM-res
 per-epoch scalars are accumulated on the device and read back once per epoch (the reference calls .item()
 three times per batch, train_gan.py:205,250-251).  Extra flags (--synthetic, --epochs, --no-graph) exist
 for smoke runs without the (git-ignored) dataset.
+
+Data parallel (not in the reference, which is single-GPU): launched under torch.distributed.run
+(`--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`) every rank holds a replica, takes every N-th batch of the
+epoch's (identically shuffled) order and averages gradients through melo_gan_amd.gan.dp.DataParallel (RCCL over
+xGMI); rank 0 logs and checkpoints.
 """
 import argparse
 import json
@@ -21,6 +26,7 @@ import torch
 
 from . import config as C
 from .dataset import GANDataset
+from .dp import DataParallel
 from .engine import GanEngine
 from .utils import seed_everything
 
@@ -80,52 +86,79 @@ def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: 
     seed_everything(cfg.get("SEED", 42))
     if not torch.cuda.is_available():
         raise RuntimeError("melo_gan_amd has no CPU path: a MI355X (ROCm) device is required")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("MELO_SHARE_GPU") == "1":     # rehearsal on a single-GPU box: ranks share the device
+            local_rank %= torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(os.environ.get("MELO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     device = torch.device("cuda", torch.cuda.current_device())
-    print(f"Using main device: {device}")
+    log = print if rank == 0 else (lambda *a, **k: None)
+    log(f"Using main device: {device}" + (f" ({world} data-parallel ranks)" if world > 1 else ""))
     B = cfg.get("BATCH_SIZE", 32)
     if synthetic:
         ds = GANDataset.synthetic(synthetic, cfg["MAX_NOTES"], cfg["NOTE_DIM"], cfg["LATENT_DIM"], cfg.get("SEED", 42), device)
     else:
         ds = GANDataset.from_split(cfg, cfg["TRAIN_SPLIT"], cfg.get("ENCODER_FEATS_TRAIN"), device)
-    print(f"Train set size: {len(ds)}")
+    log(f"Train set size: {len(ds)}")
     eng = GanEngine(cfg, ed_cfg, device, B)
     eng.init_weights(cfg.get("SEED", 42))
     load_ed_checkpoint(eng, ed_ckpt)
-    writer = _scalar_writer(cfg.get("LOG_DIR", "experiments/gan/logs"))
+    dp = DataParallel(eng, world, dist)
+    dp.broadcast_params()
+    eng.seed(cfg.get("SEED", 42) + rank)            # rank-offset Philox key: every shard draws its own noise
+    writer = _scalar_writer(cfg.get("LOG_DIR", "experiments/gan/logs")) if rank == 0 else None
     os.makedirs(cfg.get("CHECKPOINT_DIR", "experiments/gan/checkpoints"), exist_ok=True)
     os.makedirs(cfg.get("SAMPLE_DIR", "experiments/gan/samples"), exist_ok=True)
     critic_iters = cfg.get("CRITIC_ITERS", 5)
     sums = torch.zeros(3, device=device)        # sum loss_d, sum g_adv, sum g_emo (device-side accumulation)
     shuffle_gen = torch.Generator().manual_seed(cfg.get("SEED", 42))
-    print("Starting WGAN-GP Training with Emotion Guidance...")
+    log("Starting WGAN-GP Training with Emotion Guidance...")
     with torch.cuda.stream(eng.stream):
         for epoch in range(1, cfg["EPOCHS"] + 1):
             sums.zero_()
             steps = 0
-            for batch_idx, (notes, numeric, latent, emot) in enumerate(ds.batches(B, shuffle_gen)):
+            # every rank walks the same shuffled order and takes the batches rank, rank + world, ...; a trailing
+            # incomplete round is dropped so that all ranks issue the same collectives
+            usable = len(ds) // B - (len(ds) // B) % world
+            for gi, (notes, numeric, latent, emot) in enumerate(ds.batches(B, shuffle_gen)):
+                if gi >= usable:
+                    break
+                if gi % world != rank:
+                    continue
+                batch_idx = gi // world
                 eng.set_batch(notes, numeric, latent, emot)
-                eng.run("d_backward_rng", use_graph)
-                eng.run("d_update", use_graph)
+                g_step = (batch_idx + 1) % critic_iters == 0
+                dp.step(use_graph, g_step)
                 sums[0:1] += eng.loss_d_out[0:1]
-                if (batch_idx + 1) % critic_iters == 0:
-                    eng.run("g_backward_rng", use_graph)
-                    eng.run("g_update", use_graph)
+                if g_step:
                     sums[1:2] += eng.adv
                     sums[2:3] += eng.emo
                 steps += 1
             s = sums.tolist()                                    # the epoch's only device->host sync
             g_steps = max(1, steps // critic_iters)
             steps = max(1, steps)
-            print(f"Epoch {epoch}/{cfg['EPOCHS']} | D_loss: {s[0] / steps:.4f} | G_adv: {s[1] / g_steps:.4f} | "
+            log(f"Epoch {epoch}/{cfg['EPOCHS']} | D_loss: {s[0] / steps:.4f} | G_adv: {s[1] / g_steps:.4f} | "
                   f"G_emo: {s[2] / g_steps:.4f}")
+            if rank != 0:
+                continue
             writer.add_scalar("Loss/Critic", s[0] / steps, epoch)
             writer.add_scalar("Loss/Generator_Adv", s[1] / g_steps, epoch)
             writer.add_scalar("Loss/Generator_Emo", s[2] / g_steps, epoch)
             if epoch % cfg.get("SAVE_FREQ", 5) == 0:
                 save_checkpoint(eng, os.path.join(cfg["CHECKPOINT_DIR"], f"gan_epoch{epoch:04d}.pth"), epoch, full=True)
-    save_checkpoint(eng, os.path.join(cfg["CHECKPOINT_DIR"], "gan_final.pth"), full=False)
-    writer.close()
-    print("Training Complete.")
+    if rank == 0:
+        save_checkpoint(eng, os.path.join(cfg["CHECKPOINT_DIR"], "gan_final.pth"), full=False)
+        writer.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    log("Training Complete.")
     return eng
 
 

@@ -55,6 +55,31 @@ def _worker(rank, port, out):
     assert torch.equal(eng.GE.grad, g_plain)
     if rank == 0:
         torch.save({"d": eng.D.grad / WORLD, "g": eng.GE.grad / WORLD}, out)
+
+    # DataParallel.step(): the full step's launch order with the overlapped collectives.  The fake engine writes a
+    # sub-step's gradients when that sub-step "runs" and checks what must already be reduced at each point.
+    d_sum, g_sum = fd.clone(), fg.clone()
+    dist.all_reduce(d_sum)
+    dist.all_reduce(g_sum)
+    log = []
+
+    def run(name, use_graph):
+        log.append(name)
+        if name == "d_backward_rng":
+            eng.D.grad.copy_(fd)
+        elif name == "d_update":                     # the critic's (async) all-reduce must have completed
+            assert torch.equal(eng.D.grad, d_sum), "critic update before its all-reduce finished"
+        elif name == "g_backward_a2":                # produces the big slice (and part of the rest)
+            eng.GE.grad.copy_(fg)
+        elif name == "g_update":
+            assert torch.equal(eng.GE.grad, g_sum), "generator update with a partially reduced gradient"
+    eng.run = run
+    eng.big_grad_slice = lambda: (0, 5000)           # the engine's layout: big tensor first, ONE remaining range
+    dp.step(True, g_step=True)
+    assert log == ["d_backward_rng", "g_forward_rng", "d_update", "g_backward_a2", "g_backward_b", "g_update"], log
+    log.clear()
+    dp.step(True, g_step=False)
+    assert log == ["d_backward_rng", "d_update"], log
     dist.destroy_process_group()
 
 
