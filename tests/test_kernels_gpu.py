@@ -120,7 +120,9 @@ def test_convT1d_padded_output(ops):
     assert float(y[:, 16:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,inf,outf", [(64, 256, 512), (5, 6, 256), (64, 512, 8192), (7, 384, 1), (192, 256, 256), (64, 128, 4)])
+# rows > 512 take the K=1 window-GEMM instantiation (64-channel chunks) instead of the skinny kernel
+@pytest.mark.parametrize("B,inf,outf", [(64, 256, 512), (5, 6, 256), (64, 512, 8192), (7, 384, 1), (192, 256, 256), (64, 128, 4),
+                                        (1024, 256, 256), (600, 192, 320), (777, 100, 130)])
 def test_linear_fwd_dgrad_wgrad(ops, B, inf, outf):
     x, w, b = rnd(B, inf, seed=1), rnd(outf, inf, seed=2, scale=1 / math.sqrt(inf)), rnd(outf, seed=3, scale=0.1)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
