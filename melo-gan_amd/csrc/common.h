@@ -82,6 +82,61 @@ __device__ __forceinline__ float mg_apply_epilogue(const mg_epilogue& E, float v
     return v;
 }
 
+// The same epilogue for a small per-thread set of values, as whole-set passes behind ONE uniform branch each: with the
+// activation switch evaluated per element hipcc computed erff and tanhf for every element and selected afterwards.
+template <int NV>
+__device__ __forceinline__ void mg_apply_epilogue_set(const mg_epilogue& E, float (&v)[NV], const int (&n)[NV],
+                                                      const long (&di)[NV], const bool (&ok)[NV]) {
+    if (E.bias) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (ok[q]) v[q] += E.bias[n[q]];
+    }
+    if (E.scale) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (ok[q]) v[q] = v[q] * E.scale[n[q]] + E.shift[n[q]];
+    }
+    if (E.zout) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (ok[q]) E.zout[di[q]] = v[q];
+    }
+    if (E.act == MG_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = mg_act(MG_ACT_RELU, v[q]);
+    } else if (E.act == MG_ACT_LRELU) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = mg_act(MG_ACT_LRELU, v[q]);
+    } else if (E.act == MG_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = mg_act(MG_ACT_GELU, v[q]);
+    } else if (E.act == MG_ACT_TANH) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = mg_act(MG_ACT_TANH, v[q]);
+    }
+    if (E.gref) {
+        if (E.gact == MG_ACT_RELU) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_RELU, E.gref[di[q]]);
+        } else if (E.gact == MG_ACT_LRELU) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_LRELU, E.gref[di[q]]);
+        } else if (E.gact == MG_ACT_GELU) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_GELU, E.gref[di[q]]);
+        } else if (E.gact == MG_ACT_TANH) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_TANH, E.gref[di[q]]);
+        }
+    }
+    if (E.emul) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= E.emul[di[q]];
+    }
+    if (E.gscale) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= E.gscale[n[q]];
+    }
+}
+
 static inline int mg_ilog2_ceil(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

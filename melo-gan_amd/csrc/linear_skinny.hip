@@ -1,12 +1,14 @@
 // Skinny GEMM for the Linear layers of the hot path (M = batch rows <= a few hundred):
 //     y[M, N] = EPI( x[M, K] @ W^T ),   W(n, c) = w[n*w_sn + c*w_sc]
 // These layers carry almost no FLOPs (pre.2 aside) -- what matters is latency and the number of
-// workgroups.  So: one 32x32 output tile per workgroup, the K range split over the workgroup's four
-// waves (and over blockIdx.z for very deep K), operands streamed global -> registers as float4 with
-// 16 loads in flight per lane (no LDS staging, no barriers in the K loop), fp32 MFMA 32x32x2, and a
-// single LDS pass to add the four waves' partial tiles.  K-split across workgroups writes partial slabs
+// workgroups.  So: one 32x32 output tile per workgroup, the K range split over the workgroup's EIGHT
+// waves (and over blockIdx.z for very deep K) -- the dependent MFMA chain of a wave is the serial part, 64
+// cycles per 2 k -- operands streamed global -> registers as float4, all of a wave's loads in flight at
+// once (no LDS staging, no barriers in the K loop), fp32 MFMA 32x32x2, and a single LDS pass to add the
+// waves' partial tiles.  K-split across workgroups writes partial slabs
 // that a finishing kernel sums in fixed order (reproducible) and runs the epilogue on.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -23,16 +25,17 @@ struct LinP {
 };
 
 constexpr int UNR = 8;   // 8-deep k-steps per unrolled iteration: 8 float4 of A + 8 of B in flight
+constexpr int NW = 8;    // waves per workgroup (K-split inside the workgroup)
 
 template <bool W_KCONTIG, bool VEC>
-__global__ __launch_bounds__(256) void linear_skinny_kernel(const LinP p) {
-    __shared__ float tile[4][32][33];
+__global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(const LinP p) {
+    __shared__ float tile[NW][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int row = min(m0 + i, p.M - 1);          // clamped: out-of-range rows/cols are computed but never stored
     const int col = min(n0 + i, p.N - 1);
-    const int kbeg = (blockIdx.z * 4 + wave) * p.kw;
+    const int kbeg = (blockIdx.z * NW + wave) * p.kw;
     const int kend = min(kbeg + p.kw, p.K);
     const float* xr = p.x + (long)row * p.K;
     const float* wr = p.w + (long)col * p.w_sn;
@@ -77,38 +80,72 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const LinP p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     };
 
-    int k = kbeg;
-    for (; k + 8 * UNR <= kend; k += 8 * UNR) {
-        float4 a[UNR], b[UNR];
+    // a wave's whole range is at most 8*UNR deep in the layers this kernel serves: issue every load first
+    auto run = [&](auto ngroups) {
+        constexpr int G = decltype(ngroups)::value;
+        float4 a[G], b[G];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            a[u] = load_a(k + 8 * u);
-            b[u] = load_b(k + 8 * u);
+        for (int u = 0; u < G; ++u) {
+            a[u] = load_a(kbeg + 8 * u);
+            b[u] = load_b(kbeg + 8 * u);
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) mma4(a[u], b[u]);
+        for (int u = 0; u < G; ++u) mma4(a[u], b[u]);
+    };
+    const int span = kend - kbeg;
+    if (VEC && span == 8 * 8) run(std::integral_constant<int, 8>{});
+    else if (VEC && span == 8 * 4) run(std::integral_constant<int, 4>{});
+    else if (VEC && span == 8 * 2) run(std::integral_constant<int, 2>{});
+    else if (VEC && span == 8 * 1) run(std::integral_constant<int, 1>{});
+    else {
+        int k = kbeg;
+        for (; k + 8 * UNR <= kend; k += 8 * UNR) {
+            float4 a[UNR], b[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                a[u] = load_a(k + 8 * u);
+                b[u] = load_b(k + 8 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) mma4(a[u], b[u]);
+        }
+        for (; k < kend; k += 8) mma4(load_a(k), load_b(k));
     }
-    for (; k < kend; k += 8) mma4(load_a(k), load_b(k));
 
-    // ---- add the four waves' tiles ----
+    // ---- add the waves' tiles ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile[wave][(r & 3) + 8 * (r >> 2) + 4 * h][i] = acc[r];
     __syncthreads();
+    constexpr int NV = 1024 / (64 * NW);      // outputs per thread
+    float v[NV];
+    int nn[NV];
+    long di[NV];
+    bool ok[NV];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
+    for (int q = 0; q < NV; ++q) {
+        const int idx = tid + 64 * NW * q;
         const int rr = idx >> 5, cc = idx & 31;
         const int m = m0 + rr, n = n0 + cc;
-        if (m >= p.M || n >= p.N) continue;
-        float v = (tile[0][rr][cc] + tile[1][rr][cc]) + (tile[2][rr][cc] + tile[3][rr][cc]);
-        const long di = (long)m * p.N + n;
-        if (p.ksplit > 1) {
-            p.part[(long)blockIdx.z * p.M * p.N + di] = v;
-        } else {
-            v = mg_apply_epilogue(p.e, v, n, di);
-            if (p.e.accumulate) v += p.y[di];
-            p.y[di] = v;
-        }
+        ok[q] = m < p.M && n < p.N;
+        nn[q] = ok[q] ? n : 0;
+        di[q] = ok[q] ? (long)m * p.N + n : 0;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 2) t += tile[w][rr][cc] + tile[w + 1][rr][cc];
+        v[q] = t;
+    }
+    if (p.ksplit > 1) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+            if (ok[q]) p.part[(long)blockIdx.z * p.M * p.N + di[q]] = v[q];
+        return;
+    }
+    mg_apply_epilogue_set<NV>(p.e, v, nn, di, ok);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        if (!ok[q]) continue;
+        if (p.e.accumulate) v[q] += p.y[di[q]];
+        p.y[di[q]] = v[q];
     }
 }
 
@@ -126,8 +163,8 @@ __global__ void linear_finish_kernel(const float* __restrict__ part, float* __re
 int plan_ksplit(int M, int N, int K) {
     const long tiles = mg_cdiv(M, 32) * mg_cdiv(N, 32);
     int ks = 1;
-    // deepen the split while a wave would still run > 128 MFMAs (K/4/ks/2) and the grid is under ~512 WGs
-    while (ks < 32 && K / (4 * ks) > 256 && tiles * ks < 512) ks *= 2;
+    // deepen the split while a wave would still run > 64 MFMAs (K/NW/ks/2) and the grid is under ~512 WGs
+    while (ks < 32 && K / (NW * ks) > 128 && tiles * ks < 512) ks *= 2;
     return ks;
 }
 
@@ -150,7 +187,7 @@ extern "C" int mg_linear(const float* x, const float* w, float* y, int M, int K,
     p.ksplit = plan_ksplit(M, N, K);
     const bool kcontig = (w_sc == 1);
     // vector path: every wave's K range is a multiple of 8 inside K, rows 16-byte aligned
-    const int waves = 4 * p.ksplit;
+    const int waves = NW * p.ksplit;
     const bool vec = (K % (8 * waves) == 0) && ((((uintptr_t)x) & 15) == 0) &&
                      (!kcontig || ((((uintptr_t)w) & 15) == 0 && (w_sn & 3) == 0));
     p.kw = vec ? K / waves : (int)(mg_cdiv(mg_cdiv(K, waves), 8) * 8);
@@ -162,11 +199,11 @@ extern "C" int mg_linear(const float* x, const float* w, float* y, int M, int K,
     dim3 grid((unsigned)mg_cdiv(M, 32), (unsigned)mg_cdiv(N, 32), (unsigned)p.ksplit);
     hipStream_t st = (hipStream_t)stream;
     if (kcontig) {
-        if (vec) hipLaunchKernelGGL((linear_skinny_kernel<true, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((linear_skinny_kernel<true, false>), grid, dim3(256), 0, st, p);
+        if (vec) hipLaunchKernelGGL((linear_skinny_kernel<true, true>), grid, dim3(64 * NW), 0, st, p);
+        else hipLaunchKernelGGL((linear_skinny_kernel<true, false>), grid, dim3(64 * NW), 0, st, p);
     } else {
-        if (vec) hipLaunchKernelGGL((linear_skinny_kernel<false, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((linear_skinny_kernel<false, false>), grid, dim3(256), 0, st, p);
+        if (vec) hipLaunchKernelGGL((linear_skinny_kernel<false, true>), grid, dim3(64 * NW), 0, st, p);
+        else hipLaunchKernelGGL((linear_skinny_kernel<false, false>), grid, dim3(64 * NW), 0, st, p);
     }
     MG_CHECK_LAUNCH("linear_skinny_kernel");
     if (p.ksplit > 1) {

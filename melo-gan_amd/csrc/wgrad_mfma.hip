@@ -261,8 +261,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
         for (int j = 0; j < NS4; ++j) store_s(j, 0);
 #pragma unroll
         for (int j = 0; j < NL4; ++j) store_l(j, 0);
-        chunk_addr(min(1, n_chunks - 1));
-        load_all();
+        if (n_chunks > 1) {              // (a single chunk -- the Linear layers' 64-row batches -- has nothing to prefetch)
+            chunk_addr(1);
+            load_all();
+        }
         __syncthreads();
         fr[0] = frag_read(0, 0);
         MG_STAMP(1);
