@@ -182,13 +182,17 @@ int mg_dhead_wgrad(const float* ds, const float* f, const float* emb, const floa
 /* xhat[b,:] = alpha[b]*real[b,:] + (1-alpha[b])*fake[b,:]   (n = T*C elements per sample) */
 int mg_gp_interp(const float* real, const float* fake, const float* alpha, float* xhat,
                  int B, long n, mg_stream_t stream);
-/* norms[b] = ||g[b,:]||_2 ; gp = mean((norm-1)^2) ; gbar[b,:] = coef*(2/B)*(norm-1)/norm * g[b,:] */
+/* norms[b] = ||g[b,:]||_2 ; gp = mean((norm-1)^2) ; gbar[b,:] = coef*(2/B)*(norm-1)/norm * g[b,:]
+ * gp may be NULL: the mean is then left to mg_wgan_d_loss_gp (one launch fewer) */
 int mg_gp_penalty(const float* g, float* gbar, float* norms, float* gp, float coef,
                   int B, long n, mg_stream_t stream);
 
 /* ---- losses ---- */
 /* loss_d = mean(s[nb:2nb]) - mean(s[0:nb]) + lambda_gp*gp ; out[0]=loss_d out[1]=mean_real out[2]=mean_fake */
 int mg_wgan_d_loss(const float* s, const float* gp, float lambda_gp, float* out, int nb, mg_stream_t stream);
+/* the same with the penalty computed from the per-sample gradient norms: gp_out[0] = mean((norms-1)^2) */
+int mg_wgan_d_loss_gp(const float* s, const float* norms, float lambda_gp, float* out, float* gp_out, int nb,
+                      mg_stream_t stream);
 /* cross entropy over C<=32 classes: loss = mean_b(-log softmax[b,y_b]); dlogits = coef*(softmax-onehot)/B */
 int mg_softmax_ce(const float* logits, const int64_t* target, float* loss, float* dlogits,
                   float coef, int B, int C, mg_stream_t stream);
@@ -215,6 +219,13 @@ int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, 
 int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
                 float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter, mg_stream_t stream);
 
+/* The same draw WITHOUT advancing *step_counter; instead the Adam state of the optimiser whose update will consume
+ * the draws is advanced here (it is not read by this launch).  Pair it with mg_adam_flat_ticked, which applies the
+ * update without advancing its state and advances *rng_step instead: two launches per sub-step instead of four. */
+int mg_rng_fill_tick(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
+                     float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
+                     double* adam_state, float beta1, float beta2, mg_stream_t stream);
+
 /* ---- fused flat Adam / AdamW (torch.optim.Adam defaults; src/gan/train_gan.py:136-145,
  *      src/ae/train_ae.py:79).  state: double[4] = {step, beta1^step, beta2^step, unused},
  *      advanced on device so the launch is hipGraph-replayable.  grad_scale multiplies g first
@@ -222,6 +233,11 @@ int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, fl
 int mg_adam_flat(float* p, const float* g, float* m, float* v, long n,
                  float lr, float beta1, float beta2, float eps, float weight_decay,
                  double* state, float grad_scale, const float* gs_dev, mg_stream_t stream);
+/* The update alone, for a state that mg_rng_fill_tick has already advanced; advances *rng_step (see there). */
+int mg_adam_flat_ticked(float* p, const float* g, float* m, float* v, long n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay,
+                        const double* state, float grad_scale, const float* gs_dev, uint64_t* rng_step,
+                        mg_stream_t stream);
 /* out[0] = sqrt(sum g^2) ; out[1] = min(1, max_norm/(norm+1e-6))  (clip_grad_norm_, train_ae.py:121) */
 int mg_grad_norm_clip(const float* g, long n, float max_norm, float* out, void* work, size_t work_bytes,
                       mg_stream_t stream);

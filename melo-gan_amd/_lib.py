@@ -45,6 +45,7 @@ SIGNATURES = {
     "mg_gp_interp": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "mg_gp_penalty": (i32, [vp, vp, vp, vp, f32, i32, i64, vp]),
     "mg_wgan_d_loss": (i32, [vp, vp, f32, vp, i32, vp]),
+    "mg_wgan_d_loss_gp": (i32, [vp, vp, f32, vp, vp, i32, vp]),
     "mg_softmax_ce": (i32, [vp, vp, vp, vp, f32, i32, i32, vp]),
     "mg_neg_mean": (i32, [vp, vp, i32, vp]),
     "mg_fill": (i32, [vp, f32, i64, vp]),
@@ -53,7 +54,9 @@ SIGNATURES = {
     "mg_transpose_bcl_blc": (i32, [vp, vp, i32, i32, i32, vp]),
     "mg_act_bwd": (i32, [vp, vp, i32, vp, vp, i64, vp]),
     "mg_rng_fill": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp]),
+    "mg_rng_fill_tick": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, f32, f32, vp]),
     "mg_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
+    "mg_adam_flat_ticked": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp, vp]),
     "mg_grad_norm_workspace_bytes": (sz, [i64]),
     "mg_grad_norm_clip": (i32, [vp, i64, f32, vp, vp, sz, vp]),
     "mg_reparam_fwd": (i32, [vp, vp, vp, vp, i64, vp]),

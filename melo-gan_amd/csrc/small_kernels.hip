@@ -424,18 +424,26 @@ __global__ void gp_final_kernel(const float* norms, float* gp, int B) {
 }
 
 // ---------------- losses ----------------
-__global__ void wgan_d_loss_kernel(const float* s, const float* gp, float lambda_gp, float* out, int nb) {
+__global__ void wgan_d_loss_kernel(const float* s, const float* gp, const float* norms, float lambda_gp, float* out,
+                                   float* gp_out, int nb) {
     __shared__ float sh[16];
-    float r = 0.f, f = 0.f;
+    float r = 0.f, f = 0.f, q = 0.f;
     for (int b = threadIdx.x; b < nb; b += blockDim.x) {
         r += s[b];
         f += s[nb + b];
+        if (norms) {
+            const float d = norms[b] - 1.f;
+            q += d * d;
+        }
     }
     r = block_sum(r, sh);
     f = block_sum(f, sh);
+    if (norms) q = block_sum(q, sh);
     if (threadIdx.x == 0) {
         const float mr = r / (float)nb, mf = f / (float)nb;
-        out[0] = mf - mr + lambda_gp * gp[0];
+        const float pen = norms ? q / (float)nb : gp[0];
+        if (norms) gp_out[0] = pen;
+        out[0] = mf - mr + lambda_gp * pen;
         out[1] = mr;
         out[2] = mf;
     }
@@ -537,9 +545,20 @@ __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5
 struct RngJob { float* dst; long n; int kind; float p0; };   // kind 0: N(0,1); 1: U(0,1); 2: keep-mask*(1/(1-p0))
 struct RngJobs { RngJob j[4]; int njobs; };
 
-__global__ void rng_fill_kernel(const RngJobs jobs, unsigned long long seed, unsigned long long* step_ctr) {
+// tick_state (optional): the Adam state {step, beta1^step, beta2^step} of the optimiser whose update will consume
+// these draws is advanced HERE (this kernel does not read it, adam_apply_kernel -- a later launch -- does), and the
+// matching adam_apply advances step_ctr (which only this kernel reads): each of the two launches ticks the counter
+// the OTHER one reads, so neither needs a launch of its own.
+__global__ void rng_fill_kernel(const RngJobs jobs, unsigned long long seed, unsigned long long* step_ctr,
+                                double* tick_state, double beta1, double beta2) {
     const unsigned long long step = step_ctr[0];
     const int jid = blockIdx.y;
+    if (tick_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (tick_state[0] == 0.0) { tick_state[1] = 1.0; tick_state[2] = 1.0; }
+        tick_state[0] += 1.0;
+        tick_state[1] *= beta1;
+        tick_state[2] *= beta2;
+    }
     if (jid < jobs.njobs) {
         const RngJob jb = jobs.j[jid];
         for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; 4 * q < jb.n; q += (long)gridDim.x * blockDim.x) {
@@ -577,8 +596,9 @@ __global__ void adam_advance_kernel(double* state, double beta1, double beta2) {
 __global__ void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
                                   float wd, const double* __restrict__ state, float grad_scale,
-                                  const float* __restrict__ gs_dev) {
+                                  const float* __restrict__ gs_dev, unsigned long long* bump) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (bump && i == 0) bump[0] += 1;         // the Philox step counter of the draws this update consumed
     if (i >= n) return;
     const double bc1 = 1.0 - state[1];
     const double bc2 = 1.0 - state[2];
@@ -806,17 +826,27 @@ int mg_gp_interp(const float* real, const float* fake, const float* alpha, float
 
 int mg_gp_penalty(const float* g, float* gbar, float* norms, float* gp, float coef, int B, long n,
                   mg_stream_t stream) {
-    MG_CHECK_ARG(g && norms && gp && B > 0 && n > 0, "mg_gp_penalty: bad args");
+    MG_CHECK_ARG(g && norms && B > 0 && n > 0, "mg_gp_penalty: bad args");
     hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(1024), 0, ST, g, gbar, norms, coef, B, n);
-    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(256), 0, ST, (const float*)norms, gp, B);
+    if (gp) hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(256), 0, ST, (const float*)norms, gp, B);
     MG_CHECK_LAUNCH("gp_penalty");
     return MG_OK;
 }
 
 int mg_wgan_d_loss(const float* s, const float* gp, float lambda_gp, float* out, int nb, mg_stream_t stream) {
     MG_CHECK_ARG(s && gp && out && nb > 0, "mg_wgan_d_loss: bad args");
-    hipLaunchKernelGGL(wgan_d_loss_kernel, dim3(1), dim3(256), 0, ST, s, gp, lambda_gp, out, nb);
+    hipLaunchKernelGGL(wgan_d_loss_kernel, dim3(1), dim3(256), 0, ST, s, gp, (const float*)nullptr, lambda_gp, out,
+                       (float*)nullptr, nb);
     MG_CHECK_LAUNCH("wgan_d_loss");
+    return MG_OK;
+}
+
+int mg_wgan_d_loss_gp(const float* s, const float* norms, float lambda_gp, float* out, float* gp_out, int nb,
+                      mg_stream_t stream) {
+    MG_CHECK_ARG(s && norms && out && gp_out && nb > 0, "mg_wgan_d_loss_gp: bad args");
+    hipLaunchKernelGGL(wgan_d_loss_kernel, dim3(1), dim3(256), 0, ST, s, (const float*)nullptr, norms, lambda_gp, out,
+                       gp_out, nb);
+    MG_CHECK_LAUNCH("wgan_d_loss_gp");
     return MG_OK;
 }
 
@@ -875,8 +905,9 @@ int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, 
     return MG_OK;
 }
 
-int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
-                float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter, mg_stream_t stream) {
+static int rng_fill_impl(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
+                         float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
+                         double* tick_state, float beta1, float beta2, mg_stream_t stream) {
     MG_CHECK_ARG(step_counter != nullptr, "mg_rng_fill: null step counter");
     MG_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mg_rng_fill: bad dropout probability");
     RngJobs jobs{};
@@ -894,10 +925,27 @@ int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, fl
     unsigned gx = (unsigned)mg_cdiv(mg_cdiv(mx, 4), 256);
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(rng_fill_kernel, dim3(gx, n), dim3(256), 0, ST, jobs, (unsigned long long)seed,
-                       (unsigned long long*)step_counter);
-    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, ST, (unsigned long long*)step_counter);
+                       (unsigned long long*)step_counter, tick_state, (double)beta1, (double)beta2);
+    if (!tick_state)
+        hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, ST, (unsigned long long*)step_counter);
     MG_CHECK_LAUNCH("rng_fill");
     return MG_OK;
+}
+
+int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
+                           float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
+                           mg_stream_t stream) {
+    return rng_fill_impl(normal, n_normal, uniform, n_uniform, mask0, n_mask0, mask1, n_mask1, p_drop, seed,
+                         step_counter, nullptr, 0.f, 0.f, stream);
+}
+
+int mg_rng_fill_tick(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0,
+                                long n_mask0, float* mask1, long n_mask1, float p_drop, uint64_t seed,
+                                uint64_t* step_counter, double* adam_state, float beta1, float beta2,
+                                mg_stream_t stream) {
+    MG_CHECK_ARG(adam_state, "mg_rng_fill_tick: null adam_state");
+    return rng_fill_impl(normal, n_normal, uniform, n_uniform, mask0, n_mask0, mask1, n_mask1, p_drop, seed,
+                         step_counter, adam_state, beta1, beta2, stream);
 }
 
 int mg_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
@@ -906,8 +954,18 @@ int mg_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr,
     MG_CHECK_ARG(p && g && m && v && state && n > 0, "mg_adam_flat: bad args");
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST, state, (double)beta1, (double)beta2);
     hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, (const double*)state, grad_scale, gs_dev);
+                       weight_decay, (const double*)state, grad_scale, gs_dev, (unsigned long long*)nullptr);
     MG_CHECK_LAUNCH("adam_flat");
+    return MG_OK;
+}
+
+int mg_adam_flat_ticked(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, const double* state, float grad_scale, const float* gs_dev,
+                        uint64_t* rng_step, mg_stream_t stream) {
+    MG_CHECK_ARG(p && g && m && v && state && rng_step && n > 0, "mg_adam_flat_ticked: bad args");
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, state, grad_scale, gs_dev, (unsigned long long*)rng_step);
+    MG_CHECK_LAUNCH("adam_flat_ticked");
     return MG_OK;
 }
 

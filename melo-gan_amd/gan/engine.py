@@ -133,6 +133,7 @@ class FlatParams:
             o, n = self.offsets[k]
             self.p[k] = self.data[o:o + n].view(s)
         self.g: Dict[str, Tensor] = OrderedDict()
+        self.ticked = False      # Adam state already advanced by the sub-step's Philox draw (GanEngine.draw_randoms)
         if with_opt:
             self.grad = torch.zeros_like(self.data)
             self.m = torch.zeros_like(self.data)
@@ -351,9 +352,16 @@ class GanEngine:
 
     def draw_randoms(self, with_alpha: bool):
         """Production path: one Philox launch fills noise, alpha and both dropout masks (draw order of the
-        reference per sub-step: dropout masks, randn noise, rand alpha -- SURVEY section 3)."""
+        reference per sub-step: dropout masks, randn noise, rand alpha -- SURVEY section 3).  The same launch advances
+        the Adam state of the optimiser this sub-step ends with (critic when alpha is drawn, generator otherwise), and
+        that update advances the Philox step counter: no tick launches (see mg_rng_fill_tick)."""
+        fp = self.D if with_alpha else self.GE
+        # the two sub-steps draw from different Philox keys: under data parallelism the G-step's draw is issued before
+        # the critic update has advanced the step counter (DataParallel.step)
+        key = self.rng_seed if with_alpha else (self.rng_seed + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         ops.rng_fill(self.noise, self.alpha if with_alpha else None, self.dmask[0], self.dmask[1], P_DROP,
-                     self.rng_seed, self.rng_step)
+                     key, self.rng_step, tick_state=fp.state, betas=self.betas)
+        fp.ticked = True
 
     def seed(self, seed: int):
         self.rng_seed = int(seed)
@@ -508,7 +516,7 @@ class GanEngine:
         # one backward for [real | fake | x_hat] with ds = [-1/B | +1/B | 1]
         self._d_bwd_input(self.ds_d, 3 * B, None)
         ops.conv1d_dgrad(self.dZ1[2 * B:], P["conv.0.weight"], self.gx, 2)
-        ops.gp_penalty(self.gx, self.TAN0, self.norms, self.gp, self.lambda_gp)
+        ops.gp_penalty(self.gx, self.TAN0, self.norms, None, self.lambda_gp)      # mean((norm-1)^2): in wgan_d_loss
         # Weight gradients are [real,fake] activations x Wasserstein dZ + tangent activations x penalty dZ; each
         # becomes launchable as soon as its tangent exists, so they run on side streams next to the tangent pass
         # (d(lambda*gp)/d(grad_xhat) pushed forward through the masked linear critic).
@@ -527,7 +535,7 @@ class GanEngine:
         ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[2 * B:], gact=ACT_LRELU)
         ops.linear_wgrad(self.H[:2 * B], self.dU[:2 * B], G["fc.1.weight"], self.ghb, self.dU[2 * B:], db=G["fc.1.bias"])
         ops.dhead_wgrad(self.ds_d, self.Fh, self.emb, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"], 2 * B, B)
-        ops.wgan_d_loss(self.s, self.gp, self.lambda_gp, self.loss_d_out, B)
+        ops.wgan_d_loss(self.s, self.gp, self.lambda_gp, self.loss_d_out, B, norms=self.norms)
         self._join()
 
     def d_backward_rng(self):
@@ -547,9 +555,14 @@ class GanEngine:
         """(offset, numel) of decoder.pre.2.weight's gradient inside the flat G+E_num gradient buffer."""
         return self.GE.offsets["G.decoder.pre.2.weight"]
 
+    def _adam(self, fp, lr):
+        """The optimiser step; after draw_randoms() the Adam state is already advanced (fp.ticked)."""
+        ops.adam_flat(fp.data, fp.grad, fp.m, fp.v, fp.state, lr, *self.betas, grad_scale=1.0 / self.world_size,
+                      ticked_rng_step=self.rng_step if fp.ticked else None)
+        fp.ticked = False
+
     def d_update(self):
-        ops.adam_flat(self.D.data, self.D.grad, self.D.m, self.D.v, self.D.state, self.lr_d, *self.betas,
-                      grad_scale=1.0 / self.world_size)
+        self._adam(self.D, self.lr_d)
 
     # -------------------------------------------------------------------------------------
     # G-step  (src/gan/train_gan.py:211-251)
@@ -650,8 +663,7 @@ class GanEngine:
         self._join()
 
     def g_update(self):
-        ops.adam_flat(self.GE.data, self.GE.grad, self.GE.m, self.GE.v, self.GE.state, self.lr_g, *self.betas,
-                      grad_scale=1.0 / self.world_size)
+        self._adam(self.GE, self.lr_g)
 
     # -------------------------------------------------------------------------------------
     # graph capture / replay
@@ -662,6 +674,19 @@ class GanEngine:
         fn = getattr(self, name)
         if not use_graph:
             return fn()
+        # An update graph exists in two forms (Adam state advanced by the preceding draw, or by itself); a replayed
+        # graph does not run the Python that tracks which one applies, so it is tracked here by sub-step name.
+        fp_upd = {"d_update": self.D, "g_update": self.GE}.get(name)
+        key = name + ("#ticked" if fp_upd is not None and fp_upd.ticked else "")
+        try:
+            return self._run_graph(key, fn)
+        finally:
+            if name.endswith("_rng"):
+                (self.D if name.startswith("d_") else self.GE).ticked = True
+            if fp_upd is not None:
+                fp_upd.ticked = False
+
+    def _run_graph(self, name: str, fn):
         st = self._graphs.get(name)
         if st is None:
             fn()                                  # eager warm-up (allocates workspaces, sets func attrs)

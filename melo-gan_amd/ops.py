@@ -510,15 +510,22 @@ def gp_penalty(g, gbar, norms, gp, coef):
     if gbar is not None:
         _chk(gbar, "gbar", g.shape)
     _chk(norms, "norms", (B,))
-    _chk(gp, "gp")
+    if gp is not None:           # None: the mean is left to wgan_d_loss(..., norms=...)
+        _chk(gp, "gp")
     L.check(L.load().mg_gp_penalty(_p(g), _p(gbar), _p(norms), _p(gp), coef, B, g.numel() // B, _stream()),
             "mg_gp_penalty")
 
 
-def wgan_d_loss(s, gp, lambda_gp, out, nb):
+def wgan_d_loss(s, gp, lambda_gp, out, nb, norms=None):
+    """out = {loss_d, mean_real, mean_fake}.  With `norms` (per-sample gradient norms) the penalty mean((norm-1)^2) is
+    computed here and written to gp; otherwise gp is read."""
     _chk(s, "s")
     if s.numel() < 2 * nb or out.numel() < 3:
         raise ValueError("wgan_d_loss: sizes")
+    if norms is not None:
+        _chk(norms, "norms", (nb,))
+        L.check(L.load().mg_wgan_d_loss_gp(_p(s), _p(norms), lambda_gp, _p(out), _p(gp), nb, _stream()), "mg_wgan_d_loss_gp")
+        return
     L.check(L.load().mg_wgan_d_loss(_p(s), _p(gp), lambda_gp, _p(out), nb, _stream()), "mg_wgan_d_loss")
 
 
@@ -583,24 +590,40 @@ def act_bwd(dy, dx, gref=None, gact=ACT_NONE, emul=None):
     L.check(L.load().mg_act_bwd(_p(dy), _p(gref), gact, _p(emul), _p(dx), n, _stream()), "mg_act_bwd")
 
 
-def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter):
-    """One launch: normal ~ N(0,1), uniform ~ U(0,1), mask* = keep-mask/(1-p_drop); any of them may be None."""
+def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_state=None, betas=None):
+    """normal ~ N(0,1), uniform ~ U(0,1), mask* = keep-mask/(1-p_drop); any of them may be None.  Plain: draw, then
+    advance step_counter (two launches).  With tick_state (an optimiser's Adam state) and betas: ONE launch that
+    draws and advances that Adam state instead; adam_flat(..., ticked_rng_step=step_counter) later advances the counter."""
     for t in (normal, uniform, mask0, mask1):
         if t is not None:
             _chk(t, "rng tensor")
     _chk(step_counter, "step_counter", (1,), torch.int64)
     n = lambda t: 0 if t is None else t.numel()  # noqa: E731
+    if tick_state is not None:
+        _chk(tick_state, "tick_state", (4,), torch.float64)
+        L.check(L.load().mg_rng_fill_tick(_p(normal), n(normal), _p(uniform), n(uniform), _p(mask0), n(mask0), _p(mask1),
+                                          n(mask1), p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(step_counter), _p(tick_state),
+                                          betas[0], betas[1], _stream()), "mg_rng_fill_tick")
+        return
     L.check(L.load().mg_rng_fill(_p(normal), n(normal), _p(uniform), n(uniform), _p(mask0), n(mask0), _p(mask1),
                                  n(mask1), p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(step_counter), _stream()), "mg_rng_fill")
 
 
-def adam_flat(p, g, m, v, state, lr, beta1, beta2, eps=1e-8, weight_decay=0.0, grad_scale=1.0, gs_dev=None):
+def adam_flat(p, g, m, v, state, lr, beta1, beta2, eps=1e-8, weight_decay=0.0, grad_scale=1.0, gs_dev=None,
+              ticked_rng_step=None):
+    """Fused flat Adam/AdamW.  ticked_rng_step: `state` was already advanced by rng_fill(tick_state=state); apply the
+    update only and advance that Philox step counter (one launch instead of two)."""
     n = p.numel()
     for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _chk(t, nm)
         if t.numel() != n:
             raise ValueError("adam_flat: size mismatch")
     _chk(state, "state", (4,), torch.float64)
+    if ticked_rng_step is not None:
+        _chk(ticked_rng_step, "ticked_rng_step", (1,), torch.int64)
+        L.check(L.load().mg_adam_flat_ticked(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, _p(state),
+                                             grad_scale, _p(gs_dev), _p(ticked_rng_step), _stream()), "mg_adam_flat_ticked")
+        return
     L.check(L.load().mg_adam_flat(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, _p(state),
                                   grad_scale, _p(gs_dev), _stream()), "mg_adam_flat")
 
