@@ -551,18 +551,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
 }
 
 // sums the split-K slabs in fixed order and applies the fused epilogue
+// VEC: four consecutive output channels per thread with 16-byte loads / stores (N % 4 == 0, aligned tensors)
+template <bool VEC>
 __global__ void conv_finish_kernel(const float* __restrict__ part, float* __restrict__ y, long total, int Tout, int N,
                                    long ybs, int ksplit, const mg_epilogue e) {
-    const long di = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (di >= total) return;
-    float v = 0.f;
-    for (int z = 0; z < ksplit; ++z) v += part[(long)z * total + di];
-    const int n = (int)(di % N);
-    v = mg_apply_epilogue(e, v, n, di);
-    const long bt = di / N;
-    const long yi = (bt / Tout) * ybs + (bt % Tout) * N + n;
-    if (e.accumulate) v += y[yi];
-    y[yi] = v;
+    constexpr int NV = VEC ? 4 : 1;
+    const long d0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * NV;
+    if (d0 >= total) return;
+    float v[NV];
+    int nn[NV];
+    long di[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { v[q] = 0.f; di[q] = d0 + q; nn[q] = (int)((d0 + q) % N); ok[q] = true; }
+    for (int z = 0; z < ksplit; ++z) {
+        if (VEC) {
+            const float4 t = *reinterpret_cast<const float4*>(part + (long)z * total + d0);
+            v[0] += t.x; v[NV > 1 ? 1 : 0] += t.y; v[NV > 2 ? 2 : 0] += t.z; v[NV > 3 ? 3 : 0] += t.w;
+        } else {
+            v[0] += part[(long)z * total + d0];
+        }
+    }
+    mg_apply_epilogue_set<NV>(e, v, nn, di, ok);
+    const long bt = d0 / N;
+    const long yi = (bt / Tout) * ybs + (bt % Tout) * N + nn[0];
+    if (VEC) {
+        float4 o = make_float4(v[0], v[NV > 1 ? 1 : 0], v[NV > 2 ? 2 : 0], v[NV > 3 ? 3 : 0]);
+        if (e.accumulate) {
+            const float4 t = *reinterpret_cast<const float4*>(y + yi);
+            o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+        }
+        *reinterpret_cast<float4*>(y + yi) = o;
+    } else {
+        if (e.accumulate) v[0] += y[yi];
+        y[yi] = v[0];
+    }
 }
 
 template <int S, int K, bool TR2, int TM, int TN>
@@ -620,8 +643,16 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
     MG_CHECK_LAUNCH("conv_wgemm");
     if (p.ksplit > 1) {
-        hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)mg_cdiv(total, 256)), dim3(256), 0, stream,
-                           (const float*)p.part, p.y, total, p.Tout, p.N, p.ybs, p.ksplit, p.e);
+        const mg_epilogue& E = p.e;
+        auto al16 = [](const void* q) { return q == nullptr || ((((uintptr_t)q) & 15) == 0); };
+        const bool vec = (p.N % 4 == 0) && (p.ybs % 4 == 0) && al16(p.part) && al16(p.y) && al16(E.zout) && al16(E.gref) &&
+                         al16(E.emul);
+        if (vec)
+            hipLaunchKernelGGL(conv_finish_kernel<true>, dim3((unsigned)mg_cdiv(total / 4, 256)), dim3(256), 0, stream,
+                               (const float*)p.part, p.y, total, p.Tout, p.N, p.ybs, p.ksplit, p.e);
+        else
+            hipLaunchKernelGGL(conv_finish_kernel<false>, dim3((unsigned)mg_cdiv(total, 256)), dim3(256), 0, stream,
+                               (const float*)p.part, p.y, total, p.Tout, p.N, p.ybs, p.ksplit, p.e);
         MG_CHECK_LAUNCH("conv_finish");
     }
     return MG_OK;
