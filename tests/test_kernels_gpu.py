@@ -332,3 +332,35 @@ def test_rng_fill(ops):
     ops.rng_fill(c, None, None, None, 0.2, 7, c0)
     assert torch.equal(a, c) and not torch.equal(a, b)
     assert abs(torch.corrcoef(torch.stack([a, b]))[0, 1].item()) < 0.05
+
+
+def test_tick_free_draw_and_update_match_the_plain_pair(ops):
+    """rng_fill(tick_state=...) + adam_flat(ticked_rng_step=...) (one launch each) == rng_fill + adam_flat (two each):
+    same draws for the same (seed, step), same Adam state and parameters after the update, counter advanced once."""
+    n = 4096 + 3
+    torch.manual_seed(0)
+    p0, g = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    betas = (0.5, 0.9)
+
+    def run(ticked, steps=3):
+        p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        state = torch.zeros(4, dtype=torch.float64, device="cuda")
+        ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+        draws = []
+        for _ in range(steps):
+            x = torch.empty(1001, device="cuda")
+            if ticked:
+                ops.rng_fill(x, None, None, None, 0.2, 99, ctr, tick_state=state, betas=betas)
+                ops.adam_flat(p, g, m, v, state, 1e-3, *betas, ticked_rng_step=ctr)
+            else:
+                ops.rng_fill(x, None, None, None, 0.2, 99, ctr)
+                ops.adam_flat(p, g, m, v, state, 1e-3, *betas)
+            draws.append(x)
+        return p, m, v, state, ctr, draws
+
+    a, b = run(False), run(True)
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[5], b[5]):
+        assert torch.equal(x, y)
+    assert int(b[4].item()) == 3 and float(b[3][0].item()) == 3.0
