@@ -276,6 +276,32 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
 
+        # ---- secondary: the reference's schedule, CRITIC_ITERS = 5 critic updates per generator update ----
+        sched = None
+        if args.profile_steps > 0:
+            iters = max(4, min(20, args.steps // 5))
+            for k in range(2 * 5):
+                eng.set_batch(*pool[k % len(pool)])
+                dp.step(use_graph, g_step=(k % 5 == 4))
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(iters * 5):
+                eng.set_batch(*pool[k % len(pool)])
+                dp.step(use_graph, g_step=(k % 5 == 4))
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            el5 = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el5], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el5 = float(t.item())
+            sched = {"metric": "samples/s at the reference schedule (5 critic updates : 1 generator update)",
+                     "value": round(world * B_PER_GPU * iters * 5 / el5, 1), "batches": iters * 5,
+                     "ms_per_batch": round(1e3 * el5 / (iters * 5), 4)}
+
         # ---- roofline leg: the dominant kernel's launches of one step, recorded and replayed under HIP events ----
         roof = None
         if rank == 0 and args.profile_steps > 0:
@@ -327,7 +353,7 @@ def main():
                                    "(1 critic update incl. gradient penalty + 1 generator update)",
                        "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
                        "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": sched,
             "losses": {"loss_d": round(loss_d, 5), "g_adv": round(adv, 5), "g_emo": round(emo, 5)},
         }
         print(json.dumps(line), flush=True)
