@@ -301,6 +301,55 @@ def ae_case(name, B, T, latent_dim=8, n_steps=2):
     print(name, "loss", [out[f"s{i}.loss"] for i in range(n_steps)])
 
 
+def ed_train_case(name, B, T, C, n_steps=3):
+    """SURVEY f-2: the emotion discriminator's pre-training step (train_ed.py:51-82) on the reference module itself:
+    train mode (BatchNorm batch statistics), CrossEntropyLoss, AdamW(lr 2e-4, betas (0.5, 0.999), wd 0.01).
+    The classifier's dropout (p = 0.2) is live; the keep-masks nn.Dropout drew are captured and stored."""
+    ed_cfg = dict(O.default_ed_cfg(C), dropout=0.2)
+    ED = EmotionDiscriminator(ed_cfg)
+    spec, bufs = O.emotion_disc_spec(ed_cfg)
+    P = O.fill_params(spec, 9.0, O.norm_affine_names(spec))
+    for k, v in P.items():            # x4 on the matrices: logits away from 0, per-class gradients of different sizes
+        if v.dim() >= 2:
+            v.mul_(4.0)
+    Bf = {k: (torch.ones(s) if k.endswith("running_var") else torch.zeros(s)) for k, s in bufs.items()}
+    load_into(ED, P, Bf)
+    opt = torch.optim.AdamW(ED.parameters(), lr=2e-4, betas=(0.5, 0.999), weight_decay=0.01)
+    crit = nn.CrossEntropyLoss()
+    g = torch.Generator().manual_seed(11)
+    out = dict(B=B, T=T, C=C, n_steps=n_steps)
+    cap = DropCapture(ED)
+    ED.train()
+    for it in range(n_steps):
+        x = torch.rand(B, T, C, generator=g) * 2 - 1
+        y = torch.randint(0, 4, (B,), generator=g)
+        opt.zero_grad()
+        torch.manual_seed(3000 + it)
+        logits = ED(x)
+        for j, m in enumerate(cap.pop()):
+            out[f"s{it}.dm{j}"] = m.numpy().copy()
+        loss = crit(logits, y)
+        loss.backward()
+        opt.step()
+        out[f"s{it}.x"], out[f"s{it}.y"] = x.numpy().copy(), y.numpy().copy()
+        out[f"s{it}.loss"] = np.float64(loss.item())
+        out[f"s{it}.logits"] = logits.detach().numpy().copy()
+        if it == 0:
+            out["s0.grad.head_w"] = ED.classifier.head.weight.grad.numpy().copy()
+            out["s0.grad.conv0_w"] = ED.encoder.conv[0].net[0].weight.grad.numpy().copy()
+    sd = ED.state_dict()
+    for k, v in sd.items():
+        out[f"end.{k}"] = checksum(v.float())
+    out["end.head_w"] = sd["classifier.head.weight"].numpy().copy()
+    out["end.rm3"] = sd["encoder.conv.3.net.1.running_mean"].numpy().copy()
+    ED.eval()
+    cap.pop()
+    with torch.no_grad():
+        out["end.eval_logits"] = ED(torch.from_numpy(out["s0.x"])).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", [out[f"s{i}.loss"] for i in range(n_steps)])
+
+
 def midi_case(name):
     """Output contract (SURVEY f-1): the note events save_piano_roll_to_midi (src/gan/utils.py:95-161) derives from
     a generated (T, 4) tensor.  pretty_midi is absent, so a recording stand-in for the four names the function uses
@@ -342,7 +391,10 @@ def midi_case(name):
     print(name, {k: v.shape for k, v in out.items() if k.endswith("notes")})
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ed_train":     # only the f-2 fixtures
+    ed_train_case("ed_train_c4_t32_b8", 8, 32, 4)
+    ed_train_case("ed_train_c128_t16_b4", 4, 16, 128, n_steps=2)
+elif __name__ == "__main__":
     gan_case("gan_c128_t64_b4", 4, 64, 128)                    # cfg1 shape at B=4
     gan_case("gan_c4_t32_b4", 4, 32, 4)                        # reference shape (C=4) scaled down
     gan_case("gan_c4_t32_b4_bigD", 4, 32, 4, d_scale=6.0)      # critic weights x6: GP far from 1, mixed masks
@@ -352,3 +404,5 @@ if __name__ == "__main__":
     layers_case("layers_c128_t32_b2", 2, 32, 128)
     ae_case("ae_t32_b4", 4, 32)
     midi_case("midi_events")
+    ed_train_case("ed_train_c4_t32_b8", 8, 32, 4)
+    ed_train_case("ed_train_c128_t16_b4", 4, 16, 128, n_steps=2)

@@ -160,3 +160,52 @@ def test_ae_steps_match_reference():
             np.testing.assert_allclose(r["mu"].numpy(), g["s0.mu"], rtol=1e-4, atol=1e-6)
     for k, v in list(P.items()) + list(Bf.items()):
         assert close_param(k, v, g[f"end.{k}"], int(g["n_steps"]), 1e-4), k
+
+
+def ed_train_state(g):
+    """Initial state of the f-2 fixtures (tests/golden/make_golden.py::ed_train_case)."""
+    C = int(g["C"])
+    ed_cfg = dict(O.default_ed_cfg(C), dropout=0.2)
+    spec, bufs = O.emotion_disc_spec(ed_cfg)
+    P = O.fill_params(spec, 9.0, O.norm_affine_names(spec))
+    for v in P.values():
+        if v.dim() >= 2:
+            v.mul_(4.0)
+    Bf = {k: (torch.ones(s) if k.endswith("running_var") else torch.zeros(s)) for k, s in bufs.items()}
+    opt = O.AdamState(P, 2e-4, (0.5, 0.999), 1e-8, weight_decay=0.01, decoupled=True)
+    return ed_cfg, P, Bf, opt
+
+
+# conv biases in front of a train-mode BatchNorm have a mathematically zero gradient: Adam turns the rounding residue
+# into +-lr steps (in the reference too), and the running means absorb the bias
+ED_PRE_BN = tuple(f"encoder.conv.{i}.net.0.bias" for i in range(4))
+ED_RUN_MEAN = tuple(f"encoder.conv.{i}.net.1.running_mean" for i in range(4))
+
+
+@pytest.mark.parametrize("name", ["ed_train_c4_t32_b8", "ed_train_c128_t16_b4"])
+def test_ed_pretraining_steps_match_reference(name):
+    g = load(name)
+    ed_cfg, P, Bf, opt = ed_train_state(g)
+    n_steps = int(g["n_steps"])
+    for it in range(n_steps):
+        x, y = torch.from_numpy(g[f"s{it}.x"]), torch.from_numpy(g[f"s{it}.y"])
+        dm = [torch.from_numpy(g[f"s{it}.dm{j}"]).float() / 0.8 for j in range(2)]
+        r = O.ed_step(P, Bf, opt, x, y, ed_cfg, dm)
+        assert abs(r["loss"].item() - float(g[f"s{it}.loss"])) < 2e-6
+        np.testing.assert_allclose(r["logits"].numpy(), g[f"s{it}.logits"], rtol=1e-4, atol=2e-6)
+        if it == 0:
+            np.testing.assert_allclose(r["grads"]["classifier.head.weight"].numpy(), g["s0.grad.head_w"], rtol=1e-4, atol=1e-7)
+            np.testing.assert_allclose(r["grads"]["encoder.conv.0.net.0.weight"].numpy(), g["s0.grad.conv0_w"], rtol=2e-3,
+                                       atol=1e-3 * float(np.abs(g["s0.grad.conv0_w"]).max()))
+    np.testing.assert_allclose(P["classifier.head.weight"].numpy(), g["end.head_w"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(Bf["encoder.conv.3.net.1.running_mean"].numpy(), g["end.rm3"], rtol=1e-3, atol=2e-4 * n_steps)
+    for k, v in list(P.items()) + list(Bf.items()):
+        if k.endswith("num_batches_tracked"):
+            continue
+        ck, ref = checksum(v), g[f"end.{k}"]
+        if k in ED_PRE_BN or k in ED_RUN_MEAN:
+            assert np.all(np.abs(ck - ref) <= v.numel() * n_steps * 2e-4 * 1.01), k
+        else:
+            assert close_ck(ck, ref, 2e-4), (k, ck, ref)
+    logits = O.emotion_disc_fwd(P, Bf, torch.from_numpy(g["s0.x"]), ed_cfg)
+    np.testing.assert_allclose(logits.numpy(), g["end.eval_logits"], rtol=1e-3, atol=1e-4)
