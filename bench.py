@@ -49,9 +49,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="replays of the dominant kernel's launches (one step's worth each) for the roofline leg; 0 = skip")
-    ap.add_argument("--workload", default="gan", choices=["gan", "ae", "gen1"],
+    ap.add_argument("--workload", default="gan", choices=["gan", "ae", "gen1", "ed"],
                     help="gan: the headline cfg2 step (default); ae: BASELINE config 4 (VAE step, B=256, T=256, C=4); "
-                         "gen1: BASELINE config 5 (batch-1 E_num->G generation latency)")
+                         "gen1: BASELINE config 5 (batch-1 E_num->G generation latency); ed: emotion-discriminator "
+                         "pre-training step (SURVEY f-2) at the cfg2 shape")
     return ap.parse_args()
 
 
@@ -142,6 +143,36 @@ def side_workload(args):
     import melo_gan_amd  # noqa: F401
     from melo_gan_amd import ops
     torch.cuda.set_device(0)
+    if args.workload == "ed":
+        from melo_gan_amd.emotion_discriminator.engine import EdEngine
+        from melo_gan_amd.gan.config import default_ed_cfg
+        Bv = B_PER_GPU
+        cfg = dict(default_ed_cfg(C), dropout=0.2, optimizer=dict(name="AdamW", lr=2e-4, betas=[0.5, 0.999], weight_decay=0.0))
+        eng = EdEngine(cfg, "cuda", Bv, T)
+        eng.init_weights(0)
+        x = torch.rand(Bv, T, C, device="cuda") * 2 - 1
+        y = torch.randint(0, 4, (Bv,), device="cuda")
+        with torch.cuda.stream(eng.stream):
+            eng.set_batch(x, y)
+            for _ in range(max(args.warmup, 3)):
+                eng.run("backward_rng")
+                eng.run("update")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.run("backward_rng")
+                eng.run("update")
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        # conv FLOPs: forward + data-gradient (not into the input) + weight-gradient of ED conv0-3
+        gf = 2.0 * Bv * T * sum(ci * co * k for ci, co, k in eng.chans) * 3 / 1e9 - 2.0 * Bv * T * eng.chans[0][0] * eng.chans[0][1] * eng.chans[0][2] / 1e9
+        print(json.dumps({"metric": "emotion-discriminator pre-training samples/sec, batch=64 128x256 roll", "value": round(Bv * args.steps / el, 1),
+                          "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True, "dtype": "f32",
+                          "data": "synthetic", "config": {"workload": "f-2: ED train step B=64, T=256, C=128 (train-mode BN+GELU, dropout, CE, AdamW)",
+                                                          "step_gflop": round(gf, 2)},
+                          "losses": {"ce": round(eng.loss.item(), 5)}}), flush=True)
+        return
     if args.workload == "ae":
         from melo_gan_amd.ae.engine import VaeEngine
         Bv, Tv = 256, 256

@@ -135,16 +135,17 @@ int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq,
 /* ---- BatchNorm1d, training mode, fused with ReLU (src/gan/models.py:57-61, src/ae/model.py:12-21) ----
  * z: (R, C) pre-BN (R = B*T).  Computes batch mean / biased var, a = relu((z-mean)*invstd*gamma+beta),
  * saves mean/invstd, updates running_mean/var (momentum 0.1, unbiased var) -- also under no_grad.
- * act: MG_ACT_RELU or MG_ACT_NONE. */
+ * act: any MG_ACT_* (the generator uses RELU, the emotion discriminator's pre-training GELU). */
 size_t mg_bn_workspace_bytes(int C);
 int mg_bn_train_fwd(const float* z, float* a, long R, int C,
                     const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* save_mean, float* save_invstd, int act,
                     void* work, size_t work_bytes, mg_stream_t stream);
-/* backward: da (grad wrt a), a (forward output, for the ReLU mask), z.  Produces dz, dgamma, dbeta. */
+/* backward: da (grad wrt a), a (forward output: the ReLU / LeakyReLU mask, tanh'), z.  Produces dz, dgamma, dbeta.
+ * beta: only read for act = MG_ACT_GELU, whose derivative is taken at the BN output (recomputed from z); else may be NULL. */
 int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, long R, int C,
-                    const float* gamma, const float* save_mean, const float* save_invstd,
+                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                     float* dgamma, float* dbeta, int act,
                     void* work, size_t work_bytes, mg_stream_t stream);
 /* eval mode: a = act((z-running_mean)/sqrt(running_var+eps)*gamma+beta) */

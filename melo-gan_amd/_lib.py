@@ -32,7 +32,7 @@ SIGNATURES = {
     "mg_colsum": (i32, [vp, i64, i32, vp, vp, vp, sz, vp]),
     "mg_bn_workspace_bytes": (sz, [i32]),
     "mg_bn_train_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp, sz, vp]),
-    "mg_bn_train_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "mg_bn_train_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
     "mg_bn_eval_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, i32, vp]),
     "mg_bn_fold": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, vp]),
     "mg_meanT_fwd": (i32, [vp, vp, i32, i32, i32, vp]),

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, int act, long R,
                                                              int C, long rows_per, double* __restrict__ part,
-                                                             int want_sq) {
+                                                             int want_sq, const float* __restrict__ gamma = nullptr,
+                                                             const float* __restrict__ beta = nullptr) {
     __shared__ double sh[2][16][65];
     const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c0 = blockIdx.x * 64 + 4 * cq;
@@ -46,10 +47,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     const bool vec = ((C & 3) == 0) && (c0 + 3 < C);
     if (c0 < C) {
-        float mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+        float mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0}, ga[4] = {1, 1, 1, 1}, be[4] = {0, 0, 0, 0};
+        const bool pre = MODE == 1 && act == MG_ACT_GELU;       // GELU' needs the BN output, not the activation
         if (MODE == 1)
             for (int e = 0; e < 4; ++e)
-                if (c0 + e < C) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; }
+                if (c0 + e < C) {
+                    mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e];
+                    if (pre) { ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; }
+                }
         for (long r = r0 + ry; r < r1; r += 16) {
             const long i = r * C + c0;
             float xv[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0}, zv[4] = {0, 0, 0, 0};
@@ -76,9 +81,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                     s1[e] += v;
                     s2[e] += v * v;
                 } else {
-                    const double dy = (double)(xv[e] * mg_act_grad(act, av[e]));
+                    const double xh = ((double)zv[e] - (double)mu[e]) * (double)is[e];
+                    const float ref = pre ? (float)(xh * (double)ga[e] + (double)be[e]) : av[e];
+                    const double dy = (double)(xv[e] * mg_act_grad(act, ref));
                     s1[e] += dy;
-                    s2[e] += dy * (((double)zv[e] - (double)mu[e]) * (double)is[e]);
+                    s2[e] += dy * xh;
                 }
             }
         }
@@ -214,13 +221,15 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ a,
                                     const float* __restrict__ z, float* __restrict__ dz, long n, int C, long R,
                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const double* __restrict__ sums, int act) {
+                                    const float* __restrict__ invstd, const double* __restrict__ sums, int act,
+                                    const float* __restrict__ beta) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
-    const double dy = (double)(da[i] * mg_act_grad(act, a[i]));
     const double is = (double)invstd[c];
     const double xh = ((double)z[i] - (double)mean[c]) * is;
+    const float ref = act == MG_ACT_GELU ? (float)(xh * (double)gamma[c] + (double)beta[c]) : a[i];
+    const double dy = (double)(da[i] * mg_act_grad(act, ref));
     const double invR = 1.0 / (double)R;
     dz[i] = (float)((double)gamma[c] * is * (dy - sums[c] * invR - xh * sums[C + c] * invR));
 }
@@ -720,20 +729,21 @@ int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma,
 }
 
 int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, long R, int C, const float* gamma,
-                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int act,
-                    void* work, size_t work_bytes, mg_stream_t stream) {
+                    const float* beta, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                    int act, void* work, size_t work_bytes, mg_stream_t stream) {
     MG_CHECK_ARG(da && a && z && dz && gamma && save_mean && save_invstd && dgamma && dbeta, "mg_bn_train_bwd: bad args");
+    MG_CHECK_ARG(act != MG_ACT_GELU || beta, "mg_bn_train_bwd: GELU needs beta (its derivative is taken at the BN output)");
     if (!work || work_bytes < mg_bn_workspace_bytes(C)) { mg_set_error("mg_bn_train_bwd: workspace too small"); return MG_EWORK; }
     const RedPlan pl = red_plan(R);
     double* part = (double*)work;
     double* sums = part + (size_t)RED_SPLITS * 2 * C;
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), 0, ST, da, a, z, save_mean, save_invstd, act, R, C,
-                       pl.rows_per, part, 1);
+                       pl.rows_per, part, 1, gamma, beta);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C, FIN_CH)), dim3(256), 0, ST, (const double*)part, pl.nsplit, C, dgamma,
                        dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, da, a, z, dz, R * C, C, R, gamma,
-                       save_mean, save_invstd, (const double*)sums, act);
+                       save_mean, save_invstd, (const double*)sums, act, beta);
     MG_CHECK_LAUNCH("bn_train_bwd");
     return MG_OK;
 }

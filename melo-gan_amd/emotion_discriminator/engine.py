@@ -1,0 +1,224 @@
+"""Pre-training of the emotion discriminator on MI355X: one step of
+/root/reference/src/emotion_discriminator/train_ed.py:51-82 -- train-mode forward (BatchNorm batch statistics, classifier
+dropout), mean cross-entropy, backward, AdamW -- over libmelogan_hip.  The frozen, eval-mode use of the same network on
+the GAN hot path lives in melo_gan_amd.gan.engine.GanEngine.
+
+Layout: activations (B, T, C) channels-last like everywhere else; parameters / gradients / Adam moments in one flat
+fp32 buffer each (one fused AdamW launch); BatchNorm running statistics in `buf`.  Backward is hand-derived:
+  logits -> classifier (Linear, GELU, Dropout)* -> project Linear -> mean over T -> [GELU, BatchNorm(train), Conv1d]*.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_NONE
+from ..gan.engine import FlatParams, emotion_disc_spec
+
+Tensor = torch.Tensor
+
+
+class EdEngine:
+    """One replica of the emotion discriminator's training state on one GPU (input_mode == 'notes')."""
+
+    def __init__(self, cfg: dict, device="cuda", batch_size: Optional[int] = None, max_notes: Optional[int] = None):
+        if cfg.get("input_mode", "latent") != "notes":
+            raise ValueError("EdEngine: only input_mode='notes' (the convolutional encoder) is pre-trained here")
+        self.cfg = cfg
+        self.dev = d = torch.device(device)
+        self.B = B = int(batch_size or cfg.get("batch_size", 64))
+        self.T = T = int(max_notes or cfg.get("max_notes", 512))
+        self.C = C = int(cfg.get("note_dim", 4))
+        self.n_classes = int(cfg.get("n_classes", 4))
+        self.p_drop = float(cfg.get("dropout", 0.2))
+        opt = cfg.get("optimizer", {})
+        self.lr = float(opt.get("lr", 2e-4))
+        self.betas = tuple(float(b) for b in opt.get("betas", (0.9, 0.999)))
+        self.weight_decay = float(opt.get("weight_decay", 0.0))
+        self.decoupled = str(opt.get("name", "adamw")).lower() == "adamw"
+        spec, bufs, chans = emotion_disc_spec(cfg)
+        self.P = FlatParams(spec, d)
+        self.buf: Dict[str, Tensor] = OrderedDict()
+        for k, s in bufs.items():
+            self.buf[k] = torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d)
+        self.chans = chans
+        self.mlp = tuple(cfg.get("mlp_hidden", (256, 128)))
+        hid = cfg.get("notes_hidden", 256)
+        f = lambda *s: torch.empty(*s, device=d)      # noqa: E731
+        self.x = f(B, T, C)
+        self.y = torch.zeros(B, dtype=torch.int64, device=d)
+        self.z = [f(B, T, co) for (_, co, _) in chans]           # conv output (bias included), BatchNorm input
+        self.a = [f(B, T, co) for (_, co, _) in chans]           # GELU(BatchNorm(z))
+        self.dz = [f(B, T, co) for (_, co, _) in chans]
+        self.da = [f(B, T, co) for (_, co, _) in chans]
+        self.bn_mean = [f(co) for (_, co, _) in chans]
+        self.bn_invstd = [f(co) for (_, co, _) in chans]
+        self.pool, self.dpool = f(B, chans[-1][1]), f(B, chans[-1][1])
+        self.proj, self.dproj = f(B, hid), f(B, hid)
+        self.cz = [f(B, h) for h in self.mlp]                    # classifier pre-activations
+        self.ca = [f(B, h) for h in self.mlp]                    # after GELU and dropout
+        self.dcz = [f(B, h) for h in self.mlp]
+        self.dmask = [torch.ones(B, h, device=d) for h in self.mlp]      # keep-mask / (1 - p)
+        self.logits, self.dlogits = f(B, self.n_classes), f(B, self.n_classes)
+        self.loss = torch.zeros(1, device=d)
+        self.rng_step = torch.zeros(1, dtype=torch.int64, device=d)
+        self.rng_seed = int(cfg.get("seed", 42))
+        self.stream = torch.cuda.Stream(device=d)
+        self._graphs = {}
+
+    # ---- state in / out ---------------------------------------------------------------------------------
+    def init_weights(self, seed: int = 42):
+        """torch's default initialisation of the reference module (the trainer applies no weights_init to the ED):
+        Conv1d / Linear weight and bias ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)); BatchNorm gamma = 1, beta = 0."""
+        g = torch.Generator().manual_seed(seed)
+        for k, s in self.P.spec.items():
+            if ".net.1." in k:                                   # BatchNorm1d affine
+                self.P.p[k].fill_(1.0 if k.endswith("weight") else 0.0)
+                continue
+            wshape = self.P.spec[k[:-len("bias")] + "weight"] if k.endswith("bias") else s
+            bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
+            self.P.p[k].copy_((torch.rand(s, generator=g) * 2 - 1) * bound)
+        for k, v in self.buf.items():
+            v.fill_(1.0 if k.endswith("running_var") else 0.0)
+
+    def set_lr(self, lr: float):
+        """ReduceLROnPlateau: the learning rate is a launch argument baked into the captured update graph."""
+        self.lr = float(lr)
+        for k in [k for k in self._graphs if k.startswith("update")]:
+            del self._graphs[k]
+
+    def load_state(self, params: Dict[str, Tensor], buffers: Optional[Dict[str, Tensor]] = None):
+        self.P.load(params)
+        for k, v in (buffers or {}).items():
+            if k in self.buf:
+                self.buf[k].copy_(v.to(torch.float32))
+
+    def state_dict(self) -> "OrderedDict[str, Tensor]":
+        """Keys and shapes of EmotionDiscriminator.state_dict() (ed_model.py), incl. num_batches_tracked."""
+        sd = OrderedDict()
+        P = self.P.state_dict()
+        for i in range(len(self.chans)):
+            pre = f"encoder.conv.{i}.net."
+            sd[pre + "0.weight"], sd[pre + "0.bias"] = P[pre + "0.weight"], P[pre + "0.bias"]
+            sd[pre + "1.weight"], sd[pre + "1.bias"] = P[pre + "1.weight"], P[pre + "1.bias"]
+            sd[pre + "1.running_mean"] = self.buf[pre + "1.running_mean"].cpu().clone()
+            sd[pre + "1.running_var"] = self.buf[pre + "1.running_var"].cpu().clone()
+            sd[pre + "1.num_batches_tracked"] = torch.tensor(int(self.P.state[0].item()), dtype=torch.int64)
+        for k, v in P.items():
+            if k not in sd:
+                sd[k] = v
+        return sd
+
+    def set_batch(self, x: Tensor, y: Tensor):
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+
+    def set_masks(self, masks: Sequence[Tensor]):
+        """Injected classifier dropout masks, already scaled by 1/(1-p) (parity tests)."""
+        for dst, m in zip(self.dmask, masks):
+            dst.copy_(m.to(torch.float32), non_blocking=True)
+
+    def draw_masks(self):
+        """Production path: one Philox launch draws both keep-masks (scaled) and advances the AdamW state; the
+        update advances the Philox counter (mg_rng_fill_tick / mg_adam_flat_ticked)."""
+        ops.rng_fill(None, None, self.dmask[0], self.dmask[1] if len(self.dmask) > 1 else None, self.p_drop,
+                     self.rng_seed, self.rng_step, tick_state=self.P.state, betas=self.betas)
+        self.P.ticked = True
+
+    # ---- the step ---------------------------------------------------------------------------------------
+    def forward(self, train: bool = True):
+        P, x = self.P.p, self.x
+        for i in range(len(self.chans)):
+            pre = f"encoder.conv.{i}.net."
+            ops.conv1d_fwd(x, P[pre + "0.weight"], self.z[i], 1, bias=P[pre + "0.bias"])
+            if train:
+                ops.bn_train_fwd(self.z[i], self.a[i], P[pre + "1.weight"], P[pre + "1.bias"], self.buf[pre + "1.running_mean"],
+                                 self.buf[pre + "1.running_var"], self.bn_mean[i], self.bn_invstd[i], act=ACT_GELU)
+            else:
+                ops.bn_eval_fwd(self.z[i], self.a[i], P[pre + "1.weight"], P[pre + "1.bias"], self.buf[pre + "1.running_mean"],
+                                self.buf[pre + "1.running_var"], act=ACT_GELU)
+            x = self.a[i]
+        ops.meanT_fwd(x, self.pool)
+        ops.linear_fwd(self.pool, P["encoder.project.weight"], self.proj, bias=P["encoder.project.bias"])
+        feat = self.proj
+        for j in range(len(self.mlp)):
+            ops.linear_fwd(feat, P[f"classifier.net.{3 * j}.weight"], self.ca[j], bias=P[f"classifier.net.{3 * j}.bias"],
+                           zout=self.cz[j], act=ACT_GELU, emul=self.dmask[j] if train else None)
+            feat = self.ca[j]
+        ops.linear_fwd(feat, P["classifier.head.weight"], self.logits, bias=P["classifier.head.bias"])
+
+    def backward(self):
+        """Train-mode forward + cross-entropy + gradients of every parameter into self.P.grad."""
+        P, G = self.P.p, self.P.g
+        self.forward(train=True)
+        ops.softmax_ce(self.logits, self.y, self.loss, self.dlogits, 1.0)
+        n = len(self.mlp)
+        g, wname, inp = self.dlogits, "classifier.head", self.ca[n - 1]
+        for j in reversed(range(n)):
+            ops.linear_wgrad(inp, g, G[wname + ".weight"], db=G[wname + ".bias"])
+            # d/d(pre-activation) = dropout mask * GELU'(cz)
+            ops.linear_dgrad(g, P[wname + ".weight"], self.dcz[j], gref=self.cz[j], gact=ACT_GELU, emul=self.dmask[j])
+            g, wname = self.dcz[j], f"classifier.net.{3 * j}"
+            inp = self.ca[j - 1] if j > 0 else self.proj
+        ops.linear_wgrad(self.proj, g, G[wname + ".weight"], db=G[wname + ".bias"])
+        ops.linear_dgrad(g, P[wname + ".weight"], self.dproj)
+        ops.linear_wgrad(self.pool, self.dproj, G["encoder.project.weight"], db=G["encoder.project.bias"])
+        ops.linear_dgrad(self.dproj, P["encoder.project.weight"], self.dpool)
+        last = len(self.chans) - 1
+        ops.meanT_bwd(self.dpool, self.da[last])
+        for i in range(last, -1, -1):
+            pre = f"encoder.conv.{i}.net."
+            ops.bn_train_bwd(self.da[i], self.a[i], self.z[i], self.dz[i], P[pre + "1.weight"], self.bn_mean[i],
+                             self.bn_invstd[i], G[pre + "1.weight"], G[pre + "1.bias"], act=ACT_GELU, beta=P[pre + "1.bias"])
+            xin = self.a[i - 1] if i > 0 else self.x
+            ops.conv1d_wgrad(xin, self.dz[i], G[pre + "0.weight"], 1, db=G[pre + "0.bias"])
+            if i > 0:
+                ops.conv1d_dgrad(self.dz[i], P[pre + "0.weight"], self.da[i - 1], 1)
+
+    def backward_rng(self):
+        self.draw_masks()
+        self.backward()
+
+    def update(self):
+        fp = self.P
+        ops.adam_flat(fp.data, fp.grad, fp.m, fp.v, fp.state, self.lr, *self.betas,
+                      weight_decay=self.weight_decay if self.decoupled else 0.0,
+                      ticked_rng_step=self.rng_step if fp.ticked else None)
+        fp.ticked = False
+
+    def run(self, name: str, use_graph: bool = True):
+        """hipGraph replay of backward_rng / update / forward_eval (first call eager, second call captures)."""
+        fn = getattr(self, name)
+        if not use_graph:
+            return fn()
+        key = name + ("#ticked" if name == "update" and self.P.ticked else "")
+        try:
+            st = self._graphs.get(key)
+            if st is None:
+                fn()
+                self._graphs[key] = "warm"
+                return
+            if st == "warm":
+                if torch.cuda.current_stream() == torch.cuda.default_stream():
+                    raise RuntimeError("EdEngine.run: capture needs a non-default stream")
+                torch.cuda.synchronize()
+                g = ops.Graph()
+                g.begin()
+                try:
+                    fn()
+                finally:
+                    g.end()
+                self._graphs[key] = st = g
+            st.launch()
+        finally:
+            if name.endswith("_rng"):
+                self.P.ticked = True
+            if name == "update":
+                self.P.ticked = False
+
+    def forward_eval(self):
+        self.forward(train=False)

@@ -359,7 +359,8 @@ def bn_train_fwd(z, a, gamma, beta, running_mean, running_var, save_mean, save_i
     return a
 
 
-def bn_train_bwd(da, a, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta, act=ACT_RELU):
+def bn_train_bwd(da, a, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta, act=ACT_RELU, beta=None):
+    """beta is needed for act=ACT_GELU only (the derivative is taken at the BN output, recomputed from z)."""
     _chk(da, "da", z.shape)
     _chk(a, "a", z.shape)
     _chk(z, "z")
@@ -371,7 +372,9 @@ def bn_train_bwd(da, a, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta, act
         _chk(v, nm, (Cc,))
     lib = L.load()
     work = workspace(lib.mg_bn_workspace_bytes(Cc), z.device, "bn")
-    L.check(lib.mg_bn_train_bwd(_p(da), _p(a), _p(z), _p(dz), R, Cc, _p(gamma), _p(save_mean), _p(save_invstd),
+    if beta is not None:
+        _chk(beta, "beta", (Cc,))
+    L.check(lib.mg_bn_train_bwd(_p(da), _p(a), _p(z), _p(dz), R, Cc, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
                                 _p(dgamma), _p(dbeta), act, _p(work), work.numel(), _stream()), "mg_bn_train_bwd")
     return dz
 
