@@ -89,3 +89,32 @@ def test_ae_trainer_cli_smoke(tmp_path):
     spec, bufs = O.vae_spec(32, 8)
     assert set(spec) | set(bufs) <= set(final) and "encoder._linear.1.weight" in final
     assert all(torch.isfinite(v.float()).all() for v in final.values())
+
+
+def test_latent_export_matches_the_oracle_encoder(tmp_path):
+    """ae/encode.py path (SURVEY f-3): eval-mode encoder over an array whose length is not a batch multiple; mu against
+    the oracle's eval forward; checkpoint round trip through the trainer's state_dict layout."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.ae import encode as E
+    from melo_gan_amd.ae.engine import VaeEngine
+    from melo_gan_amd.ae.train_ae import state_dict
+    T, L, B = 32, 8, 4
+    spec, bufs = O.vae_spec(T, L)
+    P = O.fill_params(spec, 6.0, O.norm_affine_names(spec))
+    Bf = {k: (torch.rand(s, generator=torch.Generator().manual_seed(1)) + 0.5 if k.endswith("running_var")
+              else torch.randn(s, generator=torch.Generator().manual_seed(2)) * 0.1) for k, s in bufs.items()}
+    src = VaeEngine(dict(MAX_NOTES=T, LATENT_DIM=L, BATCH_SIZE=B, LR=1e-4, WEIGHT_DECAY=1e-5), "cuda", B)
+    src.load_state(P, Bf)
+    ckpt = os.path.join(str(tmp_path), "ae_best.pth")
+    torch.save({"epoch": 3, "model_state": state_dict(src)}, ckpt)
+    notes = torch.rand(10, T, 4, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    np.save(os.path.join(str(tmp_path), "notes.npy"), notes.numpy())
+    cfg_path = os.path.join(str(tmp_path), "ae.yaml")
+    with open(cfg_path, "w") as f:
+        f.write(f"MAX_NOTES: {T}\nLATENT_DIM: {L}\nBATCH_SIZE: {B}\nLR: 1.0e-4\nWEIGHT_DECAY: 1.0e-5\n")
+    out = os.path.join(str(tmp_path), "feats", "encoder_feats.npy")
+    E.main(["--model", ckpt, "--notes", os.path.join(str(tmp_path), "notes.npy"), "--out_file", out, "--config", cfg_path])
+    got = np.load(out)
+    _, _, mu, _ = O.vae_fwd(P, Bf, notes, torch.zeros(10, L), T, train=False)
+    assert got.shape == (10, L)
+    np.testing.assert_allclose(got, mu.numpy(), rtol=2e-3, atol=2e-5)
