@@ -269,16 +269,49 @@ __global__ __launch_bounds__(256) void meanT_fwd_kernel(const float* __restrict_
     }
 }
 
+// VEC: four channels per thread, 16-byte accesses (C % 4 == 0, aligned tensors)
+template <bool VEC>
 __global__ void meanT_bwd_kernel(const float* __restrict__ dh, float* __restrict__ dz, long n, int T, int C,
                                  const float* __restrict__ gref, int gact, const float* __restrict__ gscale) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int NV = VEC ? 4 : 1;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * NV;
     if (i >= n) return;
     const int c = (int)(i % C);
     const long b = i / ((long)T * C);
-    float v = dh[b * C + c] / (float)T;
-    if (gref) v *= mg_act_grad(gact, gref[i]);
-    if (gscale) v *= gscale[c];
-    dz[i] = v;
+    const float invT = 1.f / (float)T;
+    float v[NV], r[NV];
+    if (VEC) {
+        const float4 t = *reinterpret_cast<const float4*>(dh + b * C + c);
+        v[0] = t.x * invT; v[NV > 1 ? 1 : 0] = t.y * invT; v[NV > 2 ? 2 : 0] = t.z * invT; v[NV > 3 ? 3 : 0] = t.w * invT;
+        if (gref) {
+            const float4 g = *reinterpret_cast<const float4*>(gref + i);
+            r[0] = g.x; r[NV > 1 ? 1 : 0] = g.y; r[NV > 2 ? 2 : 0] = g.z; r[NV > 3 ? 3 : 0] = g.w;
+        }
+    } else {
+        v[0] = dh[b * C + c] * invT;
+        if (gref) r[0] = gref[i];
+    }
+    if (gref) {          // one uniform branch per activation kind (see mg_apply_epilogue_set)
+        if (gact == MG_ACT_GELU) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_GELU, r[q]);
+        } else if (gact == MG_ACT_LRELU) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_LRELU, r[q]);
+        } else if (gact == MG_ACT_RELU) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_RELU, r[q]);
+        } else if (gact == MG_ACT_TANH) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_TANH, r[q]);
+        }
+    }
+    if (gscale) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] *= gscale[c + q];
+    }
+    if (VEC) *reinterpret_cast<float4*>(dz + i) = make_float4(v[0], v[NV > 1 ? 1 : 0], v[NV > 2 ? 2 : 0], v[NV > 3 ? 3 : 0]);
+    else dz[i] = v[0];
 }
 
 // ---------------- LayerNorm (small D) ----------------
@@ -777,7 +810,11 @@ int mg_meanT_bwd(const float* dh, float* dz, int B, int T, int C, const float* g
                  mg_stream_t stream) {
     MG_CHECK_ARG(dh && dz && B > 0 && T > 0 && C > 0, "mg_meanT_bwd: bad args");
     const long n = (long)B * T * C;
-    hipLaunchKernelGGL(meanT_bwd_kernel, dim3(nblk(n)), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale);
+    auto al16 = [](const void* q) { return q == nullptr || ((((uintptr_t)q) & 15) == 0); };
+    if ((C & 3) == 0 && al16(dh) && al16(dz) && al16(gref))
+        hipLaunchKernelGGL(meanT_bwd_kernel<true>, dim3(nblk(n / 4)), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale);
+    else
+        hipLaunchKernelGGL(meanT_bwd_kernel<false>, dim3(nblk(n)), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale);
     MG_CHECK_LAUNCH("meanT_bwd");
     return MG_OK;
 }
