@@ -7,6 +7,11 @@ Instead of 4 DataLoader worker processes restarted every epoch (train_gan.py:80)
 uploaded once (MI355X has 288 GB; the reference split is 897 x 512 x 4 floats = 7 MB) and batches are
 device-side index_selects of a per-epoch permutation: shuffle=True, drop_last=True semantics.
 The slow per-file .npz path of the reference is out of scope.
+
+Splits that do not fit (or should not live) in HBM: `resident=False` keeps the note rolls in PINNED host memory and
+streams them: a batch's rows are gathered on the host into one of two pinned staging buffers and
+copied host->device on a side stream while the previous batch trains; the consumer stream waits on the copy's event.
+The small per-sample arrays (numeric features, latents, labels) stay on the device either way.
 """
 from __future__ import annotations
 
@@ -22,7 +27,7 @@ from .utils import emotion_to_index
 
 class GANDataset:
     def __init__(self, notes: np.ndarray, emotions, numeric: np.ndarray, latent: Optional[np.ndarray],
-                 latent_dim: int, device="cuda"):
+                 latent_dim: int, device="cuda", resident: bool = True):
         n = notes.shape[0]
         if not (len(emotions) == n and numeric.shape[0] == n):
             raise ValueError("NPY file length mismatch (notes, emotions, numeric_features)")
@@ -30,14 +35,19 @@ class GANDataset:
             print(f"[WARN] latent_feats length mismatch ({latent.shape[0]}) vs notes ({n}). Ignoring latent_feats.")
             latent = None
         self.n = n
-        self.notes = torch.from_numpy(np.ascontiguousarray(notes, dtype=np.float32)).to(device)
+        self.device = torch.device(device)
+        self.resident = bool(resident)
+        host_notes = torch.from_numpy(np.ascontiguousarray(notes, dtype=np.float32))
+        self.notes = host_notes.to(device) if self.resident else host_notes.pin_memory()
         self.numeric = torch.from_numpy(np.ascontiguousarray(numeric, dtype=np.float32)).to(device)
         self.latent = (torch.from_numpy(np.ascontiguousarray(latent, dtype=np.float32)) if latent is not None
                        else torch.zeros(n, latent_dim)).to(device)
         self.emot_idx = torch.tensor([emotion_to_index(e) for e in emotions], dtype=torch.int64, device=device)
+        self._copy_stream = None
 
     @classmethod
-    def from_split(cls, cfg: dict, split_csv: str, latent_feats_path: Optional[str] = None, device="cuda"):
+    def from_split(cls, cfg: dict, split_csv: str, latent_feats_path: Optional[str] = None, device="cuda",
+                   resident: Optional[bool] = None):
         """prepare_dataset of the reference trainer (train_gan.py:39-60), fast-NPY path only."""
         splits_dir = cfg.get("SPLITS_DIR", "data/splits")
         name = Path(split_csv).stem
@@ -49,23 +59,63 @@ class GANDataset:
                 f"fast-NPY arrays not found ({missing}); the per-file .npz path of the reference is not "
                 "implemented -- export the split to notes.npy / emotion.npy / numeric_features.npy")
         latent = np.load(latent_feats_path) if latent_feats_path and os.path.exists(latent_feats_path) else None
-        return cls(np.load(paths["notes"]), np.load(paths["emotion"], allow_pickle=True),
-                   np.load(paths["numeric_features"]), latent, cfg["LATENT_DIM"], device)
+        notes = np.load(paths["notes"], mmap_mode="r")
+        if resident is None:        # DATA_RESIDENT: true / false / absent = resident while the rolls take < 64 GiB
+            resident = cfg.get("DATA_RESIDENT", notes.nbytes < (64 << 30))
+        return cls(notes, np.load(paths["emotion"], allow_pickle=True),
+                   np.load(paths["numeric_features"]), latent, cfg["LATENT_DIM"], device, resident)
 
     @classmethod
-    def synthetic(cls, n: int, T: int, C: int, latent_dim: int, seed: int = 42, device="cuda"):
+    def synthetic(cls, n: int, T: int, C: int, latent_dim: int, seed: int = 42, device="cuda", resident: bool = True):
         """SURVEY section 8(d) recipe: real ~ U(-1,1), numeric ~ N(0,1), latent = 0, labels uniform over 4."""
         g = np.random.default_rng(seed)
         return cls(g.uniform(-1, 1, (n, T, C)).astype(np.float32), g.integers(0, 4, n),
-                   g.standard_normal((n, 6)).astype(np.float32), None, latent_dim, device)
+                   g.standard_normal((n, 6)).astype(np.float32), None, latent_dim, device, resident)
 
     def __len__(self):
         return self.n
 
     def batches(self, batch_size: int, generator: Optional[torch.Generator] = None):
         """One epoch: shuffled, drop_last (train_gan.py:80).  Yields device tensors."""
-        perm = torch.randperm(self.n, generator=generator).to(self.notes.device)
-        for i in range(self.n // batch_size):
+        perm_host = torch.randperm(self.n, generator=generator)
+        perm = perm_host.to(self.device)
+        nb = self.n // batch_size
+        if self.resident:
+            for i in range(nb):
+                idx = perm[i * batch_size:(i + 1) * batch_size]
+                yield (self.notes.index_select(0, idx), self.numeric.index_select(0, idx),
+                       self.latent.index_select(0, idx), self.emot_idx.index_select(0, idx))
+            return
+        # streamed: batch i+1 is gathered on the host and copied on the side stream while batch i trains
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        shape = (batch_size,) + tuple(self.notes.shape[1:])
+        stage = [torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+        dev = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        ready = [torch.cuda.Event(), torch.cuda.Event()]          # copy i landed in dev[i % 2]
+        freed = [torch.cuda.Event(), torch.cuda.Event()]          # the consumer is done with dev[i % 2]
+        cur = torch.cuda.current_stream(self.device)
+
+        def issue(i):
+            s = i % 2
+            ready[s].synchronize()                               # stage[s] is free once its previous copy completed
+            torch.index_select(self.notes, 0, perm_host[i * batch_size:(i + 1) * batch_size], out=stage[s])
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(freed[s])
+                dev[s].copy_(stage[s], non_blocking=True)
+                ready[s].record(self._copy_stream)
+
+        for s in range(2):
+            ready[s].record(cur)
+            freed[s].record(cur)
+        if nb > 0:
+            issue(0)
+        for i in range(nb):
+            if i + 1 < nb:
+                issue(i + 1)
+            s = i % 2
+            cur.wait_event(ready[s])
             idx = perm[i * batch_size:(i + 1) * batch_size]
-            yield (self.notes.index_select(0, idx), self.numeric.index_select(0, idx),
-                   self.latent.index_select(0, idx), self.emot_idx.index_select(0, idx))
+            yield (dev[s], self.numeric.index_select(0, idx), self.latent.index_select(0, idx),
+                   self.emot_idx.index_select(0, idx))
+            freed[s].record(torch.cuda.current_stream(self.device))
