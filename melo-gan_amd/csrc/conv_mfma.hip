@@ -5,8 +5,9 @@
 // With a (B, T, C) layout the im2col row of output position (b, t) is a window of
 // consecutive input rows, so nothing is materialised: a workgroup stages the input rows its
 // BM output positions need (once per 16-channel chunk) into LDS and every MFMA A-operand is
-// a strided ds_read_b32 from that window.  Weights keep the reference's layouts (see the
-// public header); a 16-channel x K-tap x BN slab is transposed into LDS as [(c,k)][n].
+// a 16-byte read of 4 channels of one window row.  Weights keep the reference's layouts (see the
+// public header); a 16-channel x K-tap x BN slab is transposed into LDS as [tap][channel quad][n][4]
+// (LDS images and the loop's schedule: comment above conv_wgemm_kernel).
 //
 //   gather   (Conv1d fwd, ConvT1d dgrad, Linear fwd/dgrad, stride-1 Conv1d dgrad with flip):
 //            window row of tap k for output t is t*S + k - (K-1)/2.
@@ -14,8 +15,9 @@
 //            phases t=2u / t=2u+1 are two stride-1 correlations over taps {0,2,4} / {1,3}
 //            sharing one input window [u-1, u+1]  (SURVEY hard part 6).
 //
-// fp32 MFMA issues one 32x32x2 every 64 cycles per SIMD, i.e. the matrix pipe -- not LDS or
-// HBM -- bounds this kernel by a wide margin: 2 A + 2 B ds_read_b32 feed 4 MFMAs (256 cycles).
+// fp32 MFMA issues one 32x32x2 every 64 cycles per SIMD: the matrix pipe -- not LDS bandwidth or
+// HBM -- is the bound, provided nothing else sits on a wave's in-order issue path between MFMAs
+// (tools/mfma_gap_fillers.hip measures what a gap tolerates).
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -24,7 +26,7 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// -DMG_STAMPS: debug build that records wall-clock stamps (100 MHz) of workgroup phases; see scratch/stamps.py
+// -DMG_STAMPS: debug build that records wall-clock stamps (100 MHz) of workgroup phases; see tools/conv_stamps.py
 #ifdef MG_STAMPS
 __device__ long long* mg_stamp_buf = nullptr;
 #define MG_STAMP(k)                                                                                        \
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         // The 4 values of one 16-B weight quad come from 4 different prefetch registers (a register transpose).
         // They are stored as two pairs (ds_write2_b32 takes two unrelated data registers): a ds_write in an MFMA
         // gap is free, while the v_movs that would gather them for one ds_write_b128 are not -- a VALU instruction
-        // behind an MFMA delays the next MFMA by ~17 cycles (scratch/mfma_rate3.hip: 64.4 -> 82 cycles per MFMA
+        // behind an MFMA delays the next MFMA by ~17 cycles (tools/mfma_gap_fillers.hip: 64.4 -> 82 cycles per MFMA
         // with one v_mov per gap; one LDS/VMEM/SALU filler per gap: 64-69).  This file is built with
         // -fno-slp-vectorize so that hipcc does not re-vectorise the pairs through v_movs.
         auto store_pair = [&](int off, float v0, float v1) {     // floats off and off+2: NOT adjacent, or hipcc

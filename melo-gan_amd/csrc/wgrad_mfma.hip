@@ -275,8 +275,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
             if (++c >= n_chunks) break;
         }
     } else if (fast) {
-        // the next chunk's S rows and L window are fetched with raw-buffer float4 loads (out-of-range slots
-        // return 0 in hardware) while the current chunk is multiplied; single LDS buffer, two barriers per chunk
+        // short sequences (TT < 16: a wave's rows straddle sequences): the pre-gap-scheduling loop.  The next chunk's
+        // S rows and L window are fetched with raw-buffer float4 loads (out-of-range slots return 0 in hardware) while
+        // the current chunk is multiplied; single LDS buffer, two barriers per chunk
         float4 sr[NS4], lr[NL4];
         auto load_chunk = [&](int c) {
             const int g = g_begin + c / p.n_ttiles, tt = c - (c / p.n_ttiles) * p.n_ttiles;
