@@ -78,3 +78,49 @@ def test_convT1d_fwd_dgrad_wgrad_vs_torch_gpu(c):
     ops.convT1d_wgrad(x, dy, dw, db=db)
     close(dw, dwr)
     close(db, dy.sum((0, 1)))
+
+
+def lin_cases(seed, n):
+    g = torch.Generator().manual_seed(seed)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=g))]  # noqa: E731
+    return [dict(M=pick([1, 4, 7, 64, 65, 192, 300, 513, 600, 1024]), K=pick([6, 8, 64, 100, 128, 256, 384, 512, 1000]),
+                 N=pick([1, 4, 31, 64, 128, 130, 256, 512, 2048]), act=pick([0, 1, 2, 3, 4]), epi=pick(["bias", "gref", "emul+acc", "zout"]))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("c", lin_cases(5, 40), ids=lambda c: "M{M}_K{K}_N{N}_act{act}_{epi}".format(**c))
+def test_linear_epilogues_vs_torch_gpu(c):
+    """Linear forward / data-gradient through both kernels (skinny GEMM for <= 512 rows, K=1 window GEMM above) with the
+    fused epilogue pieces, against torch GPU matmuls and torch activations."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    M, K, N, act, epi = c["M"], c["K"], c["N"], c["act"], c["epi"]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    actf = [lambda t: t, torch.relu, lambda t: F.leaky_relu(t, 0.2), F.gelu, torch.tanh][act]
+    z = x @ w.t() + bias
+    if epi == "bias":
+        y = torch.empty(M, N, device="cuda")
+        ops.linear_fwd(x, w, y, bias=bias, act=act)
+        close(y, actf(z))
+    elif epi == "zout":
+        y, zo = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        ops.linear_fwd(x, w, y, bias=bias, act=act, zout=zo)
+        close(zo, z)
+        close(y, actf(z))
+    elif epi == "gref":          # data-gradient with the activation derivative of the producer layer fused in
+        dy = torch.randn(M, N, device="cuda", generator=g)
+        ref = torch.randn(M, K, device="cuda", generator=g)
+        rr = ref.clone().requires_grad_(True)
+        deriv = torch.autograd.grad(actf(rr).sum(), rr)[0] if act != 4 else (1 - ref * ref)   # tanh': from the output
+        dx = torch.empty(M, K, device="cuda")
+        ops.linear_dgrad(dy, w, dx, gref=ref, gact=act)
+        close(dx, (dy @ w) * deriv)
+    else:
+        mask = (torch.rand(M, N, device="cuda", generator=g) > 0.3).float() * 1.25
+        y0 = torch.randn(M, N, device="cuda", generator=g)
+        y = y0.clone()
+        ops.linear_fwd(x, w, y, bias=bias, act=act, emul=mask, accumulate=True)
+        close(y, y0 + actf(z) * mask)
