@@ -252,8 +252,10 @@ int mg_reparam_bwd(const float* dz, const float* logvar, const float* eps, const
                    const float* dlv_kld, float* dmu, float* dlv, long n, mg_stream_t stream);
 /* mse = mean((recon-x)^2); kld = -0.5*mean(1+lv-mu^2-exp(lv)); out = {total, mse, kld};
  * drecon = 2(recon-x)/n_x ; dmu, dlv include beta-weighted KLD grads PLUS the z-path grads are added by caller */
+size_t mg_vae_loss_workspace_bytes(void);
 int mg_vae_loss(const float* recon, const float* x, long n_x, const float* mu, const float* logvar, long n_z,
-                float beta, float* out, float* drecon, float* dmu_kld, float* dlv_kld, mg_stream_t stream);
+                float beta, float* out, float* drecon, float* dmu_kld, float* dlv_kld,
+                void* work, size_t work_bytes, mg_stream_t stream);
 
 /* ---- hipGraph capture of a launch sequence issued through this library (or anything else on the stream) ---- */
 int mg_graph_begin(mg_stream_t stream);

@@ -61,7 +61,8 @@ SIGNATURES = {
     "mg_grad_norm_clip": (i32, [vp, i64, f32, vp, vp, sz, vp]),
     "mg_reparam_fwd": (i32, [vp, vp, vp, vp, i64, vp]),
     "mg_reparam_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, vp]),
-    "mg_vae_loss": (i32, [vp, vp, i64, vp, vp, i64, f32, vp, vp, vp, vp, vp]),
+    "mg_vae_loss_workspace_bytes": (sz, []),
+    "mg_vae_loss": (i32, [vp, vp, i64, vp, vp, i64, f32, vp, vp, vp, vp, vp, sz, vp]),
     "mg_graph_begin": (i32, [vp]),
     "mg_graph_end": (i32, [vp, C.POINTER(vp)]),
     "mg_graph_launch": (i32, [vp, vp]),

@@ -658,8 +658,10 @@ def vae_loss(recon, x, mu, logvar, beta, out, drecon=None, dmu=None, dlv=None):
     _chk(x, "x", recon.shape)
     _chk(mu, "mu")
     _chk(logvar, "logvar", mu.shape)
-    L.check(L.load().mg_vae_loss(_p(recon), _p(x), x.numel(), _p(mu), _p(logvar), mu.numel(), beta, _p(out),
-                                 _p(drecon), _p(dmu), _p(dlv), _stream()), "mg_vae_loss")
+    lib = L.load()
+    work = workspace(lib.mg_vae_loss_workspace_bytes(), recon.device, "vae_loss")
+    L.check(lib.mg_vae_loss(_p(recon), _p(x), x.numel(), _p(mu), _p(logvar), mu.numel(), beta, _p(out),
+                            _p(drecon), _p(dmu), _p(dlv), _p(work), work.numel(), _stream()), "mg_vae_loss")
 
 
 # ---------------------------------------------------------------------------------------
