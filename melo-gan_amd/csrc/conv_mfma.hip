@@ -51,6 +51,7 @@ struct ConvP {
     int flip;
     int tt_log2;
     int n_ttiles;
+    unsigned nt_magic;   // floor(2^32 / n_ttiles): mtile / n_ttiles = umulhi(mtile, nt_magic) (+1 correction)
     int ksplit;       // channel-chunk ranges handled by different workgroups (blockIdx.z); 1 => none
     int cps;          // chunks per split
     float* part;      // [ksplit][B*Tout*N] raw partial sums when ksplit > 1
@@ -111,8 +112,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     const int sink = 2 * buf_floats + 4 * tid;           // per-thread 16-B sink for staging slots without data
 
     const int mtile = blockIdx.x;
-    const int b0 = (mtile / p.n_ttiles) * TB;
-    const int t0 = (mtile % p.n_ttiles) * TT;
+    // mtile / n_ttiles by the host's reciprocal (one s_mul_hi instead of a ~40-instruction scalar division)
+    int mq = (int)__umulhi((unsigned)mtile, p.nt_magic);
+    if ((mq + 1) * p.n_ttiles <= mtile) ++mq;
+    const int b0 = mq * TB;
+    const int t0 = (mtile - mq * p.n_ttiles) * TT;
     const int n0 = blockIdx.y * BN;
     const int tin0 = TR2 ? (t0 - 1) : (t0 * S - PAD);
 
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                 xl[j] = row * SX + 4 * q;
                 xd[j] = buf_floats;
                 if (b < p.B && tin >= 0 && tin < p.Tin)
-                    xo[j] = (unsigned)(((long)b * p.xbs + (long)tin * p.Cin + 4 * q) * 4);
+                    xo[j] = ((unsigned)b * (unsigned)p.xbs + (unsigned)(tin * p.Cin + 4 * q)) * 4u;    // < x_bytes < 2^31
             }
         }
         // weight units.  A flipped correlation (stride-1 dgrad) is flipped HERE, in the tap plane a value is
@@ -242,11 +246,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             if constexpr (NCK) {
                 // 8 consecutive lanes = 8 consecutive columns (one conflict-free 128-B store group), then the quads
                 const int n = (u & 7) + 8 * ((u >> 3) / CG), cg = (u >> 3) % CG;
-                wg[i] = (unsigned)(((long)(n0 + n) * p.w_sn + (long)4 * cg * K) * 4);       // + c0*K per chunk
+                wg[i] = ((unsigned)(n0 + n) * (unsigned)p.w_sn + 4u * cg * K) * 4u;                 // + c0*K per chunk
                 wl[i] = xs_floats + (p.flip ? (K - 1) * WT : 0) + (cg * BN + n) * 4;          // + k*wstep per tap
             } else {
                 const int cg = u / P4, q = u - cg * P4;                   // lanes walk the contiguous (n,k) run
-                wg[i] = (unsigned)(((long)4 * cg * p.w_sc + (long)n0 * K + 4 * q) * 4);     // + c0*w_sc per chunk
+                wg[i] = (4u * cg * (unsigned)p.w_sc + (unsigned)n0 * K + 4u * q) * 4u;              // + c0*w_sc per chunk
                 if (cg < CG) {
                     wdd[i] = buf_floats;
 #pragma unroll
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                         wd[i][e] = xs_floats + (p.flip ? K - 1 - k : k) * WT + (cg * BN + n) * 4;
                     }
                 } else {
-                    wg[i] = (unsigned)((long)n0 * K * 4);                 // idle unit: any valid address
+                    wg[i] = (unsigned)n0 * K * 4u;                        // idle unit: any valid address
                 }
             }
         }
@@ -603,6 +607,7 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     p.tt_log2 = lg;
     const int TT = 1 << lg, TB = BM >> lg;
     p.n_ttiles = (int)mg_cdiv(p.Tm, TT);
+    p.nt_magic = p.n_ttiles > 1 ? (unsigned)((1ULL << 32) / (unsigned)p.n_ttiles) : 0xFFFFFFFFu;
     const int R = (TT - 1) * SA + NR;
     const size_t lds1 = ((size_t)TB * R * SX + (size_t)K * BKC * BN) * sizeof(float);
     const size_t lds = 2 * lds1 + 256 * 4 * sizeof(float);   // two buffers + the per-thread staging sink
