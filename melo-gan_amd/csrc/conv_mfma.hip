@@ -78,20 +78,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     constexpr int G8 = BKC / 8;          // MFMA groups per chunk
     constexpr int SX = BKC + 4;
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int WT = CG * BN * 4;      // floats per tap plane of the weight slab
+    // weight image: planes of [n][4] quads, one per (quad, tap).  The two weight layouts are staged differently (below)
+    // and each gets the image its stores like: NCK plane = tap*CG + quad at pitch BN quads; CNK plane = quad*K + tap at
+    // a pitch padded by (K mod 8) quads, so that lanes walking (n, tap) runs store to distinct bank quads.
+    constexpr int PP = NCK ? BN * 4 : (BN + (K == 5 ? 5 : K == 3 ? 3 : 1)) * 4;   // floats per plane
+    constexpr int PQ = NCK ? 1 : K;              // plane step per quad
+    constexpr int PK = NCK ? CG : 1;             // plane step per tap
+    constexpr int WSLAB = CG * K * PP;           // floats per chunk
     constexpr int SA = TR2 ? 1 : S;
     constexpr int NR = TR2 ? 3 : K;
     constexpr int NPH = TR2 ? 2 : 1;
     constexpr int PAD = (K - 1) / 2;
     constexpr int XQ = BKC / 4;                                        // float4 per window row
     constexpr int MAXX = (((BM - 1) * SA + NR) * XQ + 255) / 256 + 1;  // prefetch registers (float4) for X
-    // weight staging units per thread.  NCK (w[n][c][k]): unit = (column n, quad): 4K contiguous floats = K float4,
-    // transposed in registers into K 16-B stores.  CNK (w[c][n][k]): unit = (quad, float4 position in the (n,k)
-    // run): the same float4 of 4 consecutive channel rows, transposed into 4 16-B stores.
-    constexpr int UN = BN * CG / 256;
-    constexpr int P4 = BN * K / 4;
-    constexpr int UC = (CG * P4 + 255) / 256;
-    constexpr int NWR = NCK ? UN * K : UC * 4;
+    // weight staging units per thread.
+    //   NCK (w[n][c][k]): unit = (column n, quad): 4K contiguous floats = K float4 loads; the quad of tap k sits in 4
+    //     different prefetch registers and is stored as two ds_write2_b32 pairs (a register transpose through v_movs
+    //     would cost ~17 cycles per v_mov, see below).  WS = 2K stores, WL = K loads.
+    //   CNK (w[c][n][k]): unit = one quad (4 channels of one (column, tap)) = 4 dword loads from the 4 channel rows,
+    //     lanes walking the contiguous (n, k) run, and ONE 16-B store.  WS = 1, WL = 4.  (The same scheme on NCK, whose
+    //     dword loads gather 12-B pieces, measured 10 % slower than the float4 loads; on CNK it replaced float4 row
+    //     loads + 8 pair stores that were unbalanced over the threads and 4-way bank-conflicted: 3-6 % faster.)
+    constexpr int NW = NCK ? BN * CG / 256 : BN * CG * K / 256;
+    constexpr int WS = NCK ? 2 * K : 1;
+    constexpr int WL = NCK ? K : 4;
     static_assert((BN * CG) % 256 == 0, "weight units must split evenly over the workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     const int R = (TT - 1) * SA + NR;
     const int nrows = TB * R;
     const int xs_floats = nrows * SX;
-    const int buf_floats = xs_floats + K * WT;           // one {window, weight slab} buffer
+    const int buf_floats = xs_floats + WSLAB;            // one {window, weight slab} buffer
     const int sink = 2 * buf_floats + 4 * tid;           // per-thread 16-B sink for staging slots without data
 
     const int mtile = blockIdx.x;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     int bbase[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
-        bbase[ni] = xs_floats + ((lane >> 5) * BN + wn * 32 * TN + ni * 32 + (lane & 31)) * 4;
+        bbase[ni] = xs_floats + (lane >> 5) * PQ * PP + (wn * 32 * TN + ni * 32 + (lane & 31)) * 4;
 
     f32x16 acc[NPH][TM][TN];
 #pragma unroll
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                bw[k][ni] = *lds4(boff + bbase[ni] + k * WT + 2 * g * BN * 4);
+                bw[k][ni] = *lds4(boff + bbase[ni] + (2 * g * PQ + k * PK) * PP);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             if constexpr (!TR2) {
@@ -227,43 +237,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                     xo[j] = ((unsigned)b * (unsigned)p.xbs + (unsigned)(tin * p.Cin + 4 * q)) * 4u;    // < x_bytes < 2^31
             }
         }
-        // weight units.  A flipped correlation (stride-1 dgrad) is flipped HERE, in the tap plane a value is
-        // stored to, so the operand reads of the loop keep compile-time offsets.
-        constexpr int NU = NCK ? UN : UC;
-        constexpr int NP = NCK ? K : 4;      // 16-B stores (= loads) per unit
-        unsigned wg[NU];     // byte offset of the unit's first float4 (without the chunk term)
-        int wl[NU];          // NCK: float offset of the unit's tap-plane-0 store inside buffer 0
-        int wd[NU][4];       // CNK: float offset of each of the unit's 4 stores inside buffer 0 (or the sink)
-        int wdd[NU];         // CNK: what to add for buffer 1 (0 for an idle unit)
-        const int wstep = p.flip ? -WT : WT;
+        // weight units.  A flipped correlation (stride-1 dgrad) is flipped HERE, in the tap plane a quad is stored to,
+        // so the operand reads of the loop keep compile-time offsets.
+        unsigned wg[NW];     // byte offset of the unit's first load (without the chunk term)
+        int wl[NW];          // float offset inside buffer 0 of the unit's store (NCK: of its tap-0 quad)
+        const int wstep = (p.flip ? -PK : PK) * PP;                            // NCK: next tap's plane
+        const unsigned wcc = (unsigned)p.w_sc * 4u;                            // CNK: byte step between the quad's channels
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
+        for (int i = 0; i < NW; ++i) {
             const int u = tid + 256 * i;
-            wl[i] = 0;
-            wdd[i] = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wd[i][e] = sink;
             if constexpr (NCK) {
-                // 8 consecutive lanes = 8 consecutive columns (one conflict-free 128-B store group), then the quads
+                // 8 consecutive lanes = 8 consecutive columns, then the quads
                 const int n = (u & 7) + 8 * ((u >> 3) / CG), cg = (u >> 3) % CG;
-                wg[i] = ((unsigned)(n0 + n) * (unsigned)p.w_sn + 4u * cg * K) * 4u;                 // + c0*K per chunk
-                wl[i] = xs_floats + (p.flip ? (K - 1) * WT : 0) + (cg * BN + n) * 4;          // + k*wstep per tap
+                wg[i] = ((unsigned)(n0 + n) * (unsigned)p.w_sn + 4u * cg * K) * 4u;                         // + c0*K per chunk
+                wl[i] = xs_floats + ((p.flip ? (K - 1) * PK : 0) + cg * PQ) * PP + n * 4;              // + k*wstep per tap
             } else {
-                const int cg = u / P4, q = u - cg * P4;                   // lanes walk the contiguous (n,k) run
-                wg[i] = (4u * cg * (unsigned)p.w_sc + (unsigned)n0 * K + 4u * q) * 4u;              // + c0*w_sc per chunk
-                if (cg < CG) {
-                    wdd[i] = buf_floats;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = (4 * q + e) / K, k = 4 * q + e - n * K;
-                        wd[i][e] = xs_floats + (p.flip ? K - 1 - k : k) * WT + (cg * BN + n) * 4;
-                    }
-                } else {
-                    wg[i] = (unsigned)n0 * K * 4u;                        // idle unit: any valid address
-                }
+                const int cg = u / (BN * K), e = u - cg * (BN * K);
+                const int n = e / K, k = e - n * K;
+                wg[i] = (4u * cg * (unsigned)p.w_sc + (unsigned)(n0 * K + e)) * 4u;                          // + c0*w_sc per chunk
+                wl[i] = xs_floats + (cg * PQ + (p.flip ? K - 1 - k : k) * PK) * PP + n * 4;
             }
         }
-        f32x4 xr[MAXX], wr[NU * NP];
+        f32x4 xr[MAXX], wr[NCK ? NW * K : NW];
         auto bload = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned soff) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
             return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
@@ -271,40 +266,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         auto x_soff = [&](int c0) { return 4u * (unsigned)c0; };
         auto w_soff = [&](int c0) { return (unsigned)((NCK ? (long)c0 * K : (long)c0 * p.w_sc) * 4); };
         auto load_x = [&](int j, unsigned soff) { xr[j] = bload(xrsrc, xo[j], soff); };
-        auto load_w = [&](int i, int part, unsigned soff) {
-            const unsigned step = NCK ? 16u : (unsigned)p.w_sc * 4u;      // next float4 of the run / next channel row
-            wr[i * NP + part] = bload(wrsrc, wg[i] + (unsigned)part * step, soff);
+        auto load_w = [&](int i, int part, unsigned soff) {      // NCK: float4 `part` of the run; CNK: channel `part`
+            if constexpr (NCK) wr[i * K + part] = bload(wrsrc, wg[i] + 16u * (unsigned)part, soff);
+            else wr[i][part] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, wg[i], soff + (unsigned)part * wcc, 0));
         };
         auto store_x = [&](int j, int buf) { *lds4(xl[j] + (buf ? xd[j] : 0)) = xr[j]; };
-        // one 16-B store of weight unit i: NCK part = tap k (element cc*K + k of the unit's 4K floats, cc = channel
-        // in the quad); CNK part = element e of the float4, i.e. (n, k) pair number 4q+e, from the 4 channel rows
-        // The 4 values of one 16-B weight quad come from 4 different prefetch registers (a register transpose).
-        // They are stored as two pairs (ds_write2_b32 takes two unrelated data registers): a ds_write in an MFMA
-        // gap is free, while the v_movs that would gather them for one ds_write_b128 are not -- a VALU instruction
-        // behind an MFMA delays the next MFMA by ~17 cycles (tools/mfma_gap_fillers.hip: 64.4 -> 82 cycles per MFMA
-        // with one v_mov per gap; one LDS/VMEM/SALU filler per gap: 64-69).  This file is built with
-        // -fno-slp-vectorize so that hipcc does not re-vectorise the pairs through v_movs.
-        auto store_pair = [&](int off, float v0, float v1) {     // floats off and off+2: NOT adjacent, or hipcc
-            float* d = smem + off;                               // merges the pair into v_movs + ds_write_b64
-            d[0] = v0; d[2] = v1;
-        };
-        auto wq = [&](int i, int part, int cc) -> float {      // value of channel cc of weight quad `part` of unit i
-            if constexpr (NCK) return wr[i * K + (cc * K + part) / 4][(cc * K + part) % 4];
-            else return wr[i * 4 + cc][part];
-        };
-        auto store_w = [&](int i, int part, int half, int buf) {
-            int off;
-            if constexpr (NCK) off = wl[i] + part * wstep + (buf ? buf_floats : 0);
-            else off = wd[i][part] + (buf ? wdd[i] : 0);
-            store_pair(off + half, wq(i, part, half), wq(i, part, half + 2));
+        // NCK: the 4 values of a tap's quad come from 4 different prefetch registers.  They are stored as two pairs
+        // (ds_write2_b32 takes two unrelated data registers): a ds_write in an MFMA gap is free, while the v_movs that
+        // would gather them for one ds_write_b128 are not -- a VALU instruction behind an MFMA delays the next MFMA by
+        // ~17 cycles (tools/mfma_gap_fillers.hip: 64.4 -> 82 cycles per MFMA with one v_mov per gap; one LDS/VMEM/SALU
+        // filler per gap: 64-69).  This file is built with -fno-slp-vectorize so that hipcc does not re-vectorise the
+        // pairs through v_movs; the pair is floats off and off+2, NOT adjacent, or it is merged into a ds_write_b64.
+        auto store_w = [&](int i, int part, int buf) {           // NCK: part = 2*tap + half; CNK: part = 0
+            if constexpr (NCK) {
+                const int k = part >> 1, half = part & 1;
+                float* d = smem + wl[i] + k * wstep + (buf ? buf_floats : 0) + half;
+                const int e0 = half * K + k, e1 = (half + 2) * K + k;        // element cc*K + k of the unit's 4K floats
+                d[0] = wr[i * K + e0 / 4][e0 % 4];
+                d[2] = wr[i * K + e1 / 4][e1 % 4];
+            } else {
+                *lds4(wl[i] + (buf ? buf_floats : 0)) = wr[i];
+            }
         };
         auto load_chunk = [&](int c0) {
 #pragma unroll
             for (int j = 0; j < MAXX; ++j) load_x(j, x_soff(c0));
 #pragma unroll
-            for (int i = 0; i < NU; ++i)
+            for (int i = 0; i < NW; ++i)
 #pragma unroll
-                for (int part = 0; part < NP; ++part) load_w(i, part, w_soff(c0));
+                for (int part = 0; part < WL; ++part) load_w(i, part, w_soff(c0));
         };
         // Gap-scheduled loop over two LDS buffers.  A chunk is NSLOT slots of 4 MFMAs (one tap x one channel
         // group).  A wave issues in order and each MFMA waits 64 cycles for its predecessor on the same
@@ -318,11 +308,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
         // the end the last chunk is re-staged into the idle buffer; slots without data write to the sink.
         constexpr int NQ = TR2 ? 5 : K;             // MFMA quads per channel group
         constexpr int NSLOT = G8 * NQ;
-        constexpr int NGAP = (NSLOT - 1) * 3;
-        // staging ops, one memory instruction each.  X slot j: store, then (next op, so not in the same gap: a load
-        // that overwrites the registers a store in front of it still reads costs ~20 cycles) its reload.  Weight
-        // unit i: 2*NP pair stores, then its NP reloads.
-        constexpr int NOPS = 2 * MAXX + NU * 3 * NP;
+        constexpr int NGAP = NSLOT * 3;             // staging gaps per chunk; stores only in the first (NSLOT-1)*3
+        // Staging ops, one memory instruction each, over the units X slot 0..MAXX-1 (a 16-B store + a 16-B reload)
+        // and weight unit 0..NW-1 (WS stores + WL reloads), in the order
+        //     S(0) | S(1) L(0) | S(2) L(1) | ... | L(last)
+        // so that a unit's reload never shares a gap with its own store (a load overwriting registers that a store
+        // right in front of it still reads cost ~20 cycles in tools/mfma_gap_fillers.hip) and the tail of the list
+        // is loads only: those may sit behind the chunk's barrier, in the gaps of the last slot.
+        constexpr int NOPS = 2 * MAXX + NW * (WS + WL);
+        constexpr int WBASE = 2 * MAXX + WS;        // first op behind {S(w0), L(x last)}
+        constexpr int LAST_STORE = NW > 1 ? WBASE + (NW - 2) * (WS + WL) + WS - 1 : WBASE - 2;
+        // ops spread evenly over the gaps, unless that would put a store behind the barrier: then the ops up to the
+        // last store fill the gaps in front of it and the trailing loads the gaps of the last slot
+        constexpr int GPRE = (NSLOT - 1) * 3;
+        constexpr bool EVEN = LAST_STORE * NGAP / NOPS < GPRE;
+        auto gap_of = [](int o) {
+            if (EVEN) return o * NGAP / NOPS;
+            return o <= LAST_STORE ? o * GPRE / (LAST_STORE + 1) : GPRE + (o - LAST_STORE - 1) * 3 / (NOPS - LAST_STORE - 1);
+        };
         static_assert(NSLOT % 2 == 0, "operand register sets alternate per slot");
         f32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int boff, int slot, f32x4 (&A)[TM], f32x4 (&Bv)[TN]) {
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) A[mi] = *lds4(boff + abase[mi] + row * SX + 8 * g);
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) Bv[ni] = *lds4(boff + bbase[ni] + q * WT + 2 * g * BN * 4);
+            for (int ni = 0; ni < TN; ++ni) Bv[ni] = *lds4(boff + bbase[ni] + (2 * g * PQ + q * PK) * PP);
         };
         const int c_last = c_end - BKC;
         auto chunk = [&](auto parity, int c0) {
@@ -359,27 +362,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
 #endif
                     if (sl + 1 < NSLOT) frag_read(cur, sl + 1, fa[(sl + 1) & 1], fb[(sl + 1) & 1]);
                     else frag_read(oth, 0, fa[0], fb[0]);
-                } else if (sl < NSLOT - 1) {
+                } else {
                     const int gap = sl * 3 + s4 - 1;
 #pragma unroll
                     for (int o = 0; o < NOPS; ++o) {
-                        if (o * NGAP / NOPS != gap) continue;
-                        if (o < 2 * MAXX) {
-#ifndef MG_EXP_NOXSTORE
-                            if (o % 2 == 0) store_x(o / 2, 1 - P);
-#endif
-#ifndef MG_EXP_NOLOADS
-                            if (o % 2 == 1) load_x(o / 2, xs);
-#endif
+                        if (gap_of(o) != gap) continue;
+                        // decode the op list above: unit stored / unit reloaded (X slots first), and which part
+                        int su = -1, lu = -1, part = 0;
+                        if (o < 2 * MAXX - 1) {
+                            if (o == 0) su = 0;
+                            else if (o & 1) su = (o + 1) / 2;
+                            else lu = o / 2 - 1;
+                        } else if (o < WBASE - 1) {
+                            su = MAXX;
+                            part = o - (2 * MAXX - 1);
+                        } else if (o == WBASE - 1) {
+                            lu = MAXX - 1;
                         } else {
-                            const int i = (o - 2 * MAXX) / (3 * NP), r = (o - 2 * MAXX) % (3 * NP);
-#ifndef MG_EXP_NOWSTORE
-                            if (r < 2 * NP) store_w(i, r / 2, r % 2, 1 - P);
-#endif
-#ifndef MG_EXP_NOLOADS
-                            if (r >= 2 * NP) load_w(i, r - 2 * NP, ws);
-#endif
+                            const int i = (o - WBASE) / (WS + WL), r = (o - WBASE) % (WS + WL);
+                            if (i < NW - 1 && r < WS) { su = MAXX + i + 1; part = r; }
+                            else { lu = MAXX + i; part = i < NW - 1 ? r - WS : r; }
                         }
+                        if (su >= 0) {
+                            if (su < MAXX) {
+#ifndef MG_EXP_NOXSTORE
+                                store_x(su, 1 - P);
+#endif
+                            } else {
+#ifndef MG_EXP_NOWSTORE
+                                store_w(su - MAXX, part, 1 - P);
+#endif
+                            }
+                        }
+#ifndef MG_EXP_NOLOADS
+                        if (lu >= 0) {
+                            if (lu < MAXX) load_x(lu, xs);
+                            else load_w(lu - MAXX, part, ws);
+                        }
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -390,12 +410,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < MAXX; ++j) store_x(j, 0);
 #pragma unroll
-        for (int i = 0; i < NU; ++i)
+        for (int i = 0; i < NW; ++i)
 #pragma unroll
-            for (int part = 0; part < NP; ++part) {
-                store_w(i, part, 0, 0);
-                store_w(i, part, 1, 0);
-            }
+            for (int part = 0; part < WS; ++part) store_w(i, part, 0);
         load_chunk(min(c_begin + BKC, c_last));
         __syncthreads();
         MG_STAMP(2);
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                 }
                 float v = 0.f;
                 if (n0 + n < p.N && c0 + c < c_end) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
-                smem[xs_floats + (p.flip ? K - 1 - k : k) * WT + ((c >> 2) * BN + n) * 4 + (c & 3)] = v;
+                smem[xs_floats + ((c >> 2) * PQ + (p.flip ? K - 1 - k : k) * PK) * PP + n * 4 + (c & 3)] = v;
             }
             __syncthreads();
             const int ng = min(G8, (c_end - c0 + 7) >> 3);
@@ -609,7 +626,8 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     p.n_ttiles = (int)mg_cdiv(p.Tm, TT);
     p.nt_magic = p.n_ttiles > 1 ? (unsigned)((1ULL << 32) / (unsigned)p.n_ttiles) : 0xFFFFFFFFu;
     const int R = (TT - 1) * SA + NR;
-    const size_t lds1 = ((size_t)TB * R * SX + (size_t)K * BKC * BN) * sizeof(float);
+    constexpr int PP = (BN + (K == 5 ? 5 : K == 3 ? 3 : 1)) * 4;     // the larger (padded, CNK) weight plane of the kernel
+    const size_t lds1 = ((size_t)TB * R * SX + (size_t)(BKC / 4) * K * PP) * sizeof(float);
     const size_t lds = 2 * lds1 + 256 * 4 * sizeof(float);   // two buffers + the per-thread staging sink
     if (lds > 160 * 1024) {
         mg_set_error("conv_wgemm: LDS request %zu too large", lds);
