@@ -212,6 +212,21 @@ int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, mg_st
 int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, float* dx, long n,
                mg_stream_t stream);
 
+/* ---- batch staging (the device side of the DataLoader collate + .to(device) of src/gan/train_gan.py:80,172-178):
+ *      for every job, dst row r <- src row (idx ? idx[r] : r) for r < n_rows, ALL jobs in one launch.  Rows are
+ *      row_bytes long (a multiple of 4; 16-byte aligned rows take the 16-byte path), dst rows are dense.  idx is a
+ *      device array of n_rows int64 indices, clamped into [0, src_rows) on the device (an out-of-range index never
+ *      reads outside the source). */
+#define MG_MAX_STAGE_JOBS 8
+typedef struct mg_stage_job {
+    const void* src;
+    void* dst;
+    const int64_t* idx; /* NULL: straight copy of the first n_rows rows */
+    long row_bytes;
+    long src_rows;
+} mg_stage_job;
+int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t stream);
+
 /* ---- per-step random inputs (replaces torch.randn / torch.rand / nn.Dropout's bernoulli draws:
  *      src/gan/train_gan.py:188,218; src/gan/utils.py:76; src/gan/feature_encoder.py:34) in ONE launch:
  *      normal[n_normal] ~ N(0,1), uniform[n_uniform] ~ U(0,1), mask{0,1} = keep-mask * 1/(1-p_drop).

@@ -538,6 +538,27 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int sld, int sof
     float* d = dst + (long)r * dld + doff + j;
     *d = accumulate ? *d + v : v;
 }
+struct StageJobs { mg_stage_job j[MG_MAX_STAGE_JOBS]; };
+// blockIdx.z = job, blockIdx.y = destination row, blockIdx.x strides over the row
+__global__ void stage_rows_kernel(const StageJobs J, int n_rows) {
+    const mg_stage_job job = J.j[blockIdx.z];
+    const int r = blockIdx.y;
+    long sr = r;
+    if (job.idx) {
+        sr = job.idx[r];
+        sr = sr < 0 ? 0 : (sr >= job.src_rows ? job.src_rows - 1 : sr);
+    }
+    const char* s = static_cast<const char*>(job.src) + sr * job.row_bytes;
+    char* d = static_cast<char*>(job.dst) + (long)r * job.row_bytes;
+    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)job.row_bytes) & 15) == 0) {
+        const long n = job.row_bytes >> 4;
+        for (long i = first; i < n; i += stride) reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+    } else {
+        const long n = job.row_bytes >> 2;
+        for (long i = first; i < n; i += stride) reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
+    }
+}
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int L) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
@@ -966,6 +987,27 @@ int mg_copy_cols(const float* src, int sld, int soff, float* dst, int dld, int d
     hipLaunchKernelGGL(copy_cols_kernel, dim3(nblk((long)rows * ncols)), dim3(256), 0, ST, src, sld, soff, dst, dld, doff,
                        rows, ncols, accumulate);
     MG_CHECK_LAUNCH("copy_cols");
+    return MG_OK;
+}
+
+int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t stream) {
+    MG_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= MG_MAX_STAGE_JOBS && n_rows > 0 && n_rows <= 65535,
+                 "mg_stage_rows: need 1..%d jobs and 1..65535 rows", MG_MAX_STAGE_JOBS);
+    StageJobs J = {};
+    long widest = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const mg_stage_job& j = jobs[i];
+        MG_CHECK_ARG(j.src && j.dst && j.row_bytes > 0 && (j.row_bytes & 3) == 0 && j.src_rows > 0 &&
+                         ((((uintptr_t)j.src | (uintptr_t)j.dst)) & 3) == 0 && (j.idx || j.src_rows >= n_rows),
+                     "mg_stage_rows: job %d: rows must be non-empty multiples of 4 bytes, 4-byte aligned, and the source "
+                     "must hold n_rows rows when it is not indexed", i);
+        J.j[i] = j;
+        widest = j.row_bytes > widest ? j.row_bytes : widest;
+    }
+    long bx = mg_cdiv(widest >> 4, 256);
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)bx, (unsigned)n_rows, (unsigned)n_jobs), dim3(256), 0, ST, J, n_rows);
+    MG_CHECK_LAUNCH("stage_rows");
     return MG_OK;
 }
 

@@ -25,6 +25,30 @@ import torch
 from .utils import emotion_to_index
 
 
+class Batch:
+    """One batch of the epoch's order.  Nothing is gathered until it is used: `stage(engine)` gathers the rows straight
+    into the engine's input buffers in one launch; iterating / unpacking it yields the four gathered device tensors
+    (notes, numeric, latent, emot_idx) like a DataLoader batch.  A rank that skips the batch pays nothing."""
+
+    def __init__(self, ds, idx, notes=None):
+        self.ds, self.idx, self.notes = ds, idx, notes      # notes: already gathered (streamed mode)
+
+    def stage(self, eng):
+        ds = self.ds
+        if self.notes is None:
+            eng.set_batch(ds.notes, ds.numeric, ds.latent, ds.emot_idx, idx=self.idx)
+        else:
+            eng.set_batch(self.notes, ds.numeric, ds.latent, ds.emot_idx, idx=self.idx, real_idx=None)
+
+    def tensors(self):
+        ds, idx = self.ds, self.idx
+        notes = self.notes if self.notes is not None else ds.notes.index_select(0, idx)
+        return (notes, ds.numeric.index_select(0, idx), ds.latent.index_select(0, idx), ds.emot_idx.index_select(0, idx))
+
+    def __iter__(self):
+        return iter(self.tensors())
+
+
 class GANDataset:
     def __init__(self, notes: np.ndarray, emotions, numeric: np.ndarray, latent: Optional[np.ndarray],
                  latent_dim: int, device="cuda", resident: bool = True):
@@ -82,9 +106,7 @@ class GANDataset:
         nb = self.n // batch_size
         if self.resident:
             for i in range(nb):
-                idx = perm[i * batch_size:(i + 1) * batch_size]
-                yield (self.notes.index_select(0, idx), self.numeric.index_select(0, idx),
-                       self.latent.index_select(0, idx), self.emot_idx.index_select(0, idx))
+                yield Batch(self, perm[i * batch_size:(i + 1) * batch_size])
             return
         # streamed: batch i+1 is gathered on the host and copied on the side stream while batch i trains
         if self._copy_stream is None:
@@ -116,6 +138,5 @@ class GANDataset:
             s = i % 2
             cur.wait_event(ready[s])
             idx = perm[i * batch_size:(i + 1) * batch_size]
-            yield (dev[s], self.numeric.index_select(0, idx), self.latent.index_select(0, idx),
-                   self.emot_idx.index_select(0, idx))
+            yield Batch(self, idx, notes=dev[s])
             freed[s].record(torch.cuda.current_stream(self.device))

@@ -334,7 +334,21 @@ class GanEngine:
             ed[k] = v.cpu().clone()
         return {"G": out_g, "E_num": E, "D": self.D.state_dict(), "ED": ed}
 
-    def set_batch(self, real: Tensor, numeric: Tensor, latent: Optional[Tensor], emot_idx: Tensor):
+    def set_batch(self, real: Tensor, numeric: Tensor, latent: Optional[Tensor], emot_idx: Tensor,
+                  idx: Optional[Tensor] = None, real_idx="same"):
+        """Stage one batch into the engine's input buffers.  Device sources go through ONE mg_stage_rows launch; with
+        `idx` (int64 device tensor of B rows) the sources are whole resident arrays and the batch is gathered from
+        them (real_idx=None: `real` alone is already a gathered batch).  Host sources take torch's copies."""
+        srcs = [(real, self.X0, idx if real_idx == "same" else real_idx), (numeric, self.numeric, idx)]
+        if latent is not None and self.latent_dim > 0:
+            srcs.append((latent, self.latent, idx))
+        srcs.append((emot_idx, self.emot_idx, idx))
+        if all(s.is_cuda and s.is_contiguous() and s.dtype == d.dtype and s.shape[1:] == d.shape[1:] and
+               (i is not None or s.shape[0] == self.B) for s, d, i in srcs):
+            ops.stage_rows(srcs, self.B)
+            return
+        if idx is not None:
+            raise ValueError("set_batch: gathering by idx needs contiguous device sources of the engine's dtypes")
         self.X0[:self.B].copy_(real, non_blocking=True)
         self.numeric.copy_(numeric, non_blocking=True)
         if latent is not None:

@@ -126,13 +126,13 @@ def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: 
             # every rank walks the same shuffled order and takes the batches rank, rank + world, ...; a trailing
             # incomplete round is dropped so that all ranks issue the same collectives
             usable = len(ds) // B - (len(ds) // B) % world
-            for gi, (notes, numeric, latent, emot) in enumerate(ds.batches(B, shuffle_gen)):
+            for gi, batch in enumerate(ds.batches(B, shuffle_gen)):
                 if gi >= usable:
                     break
                 if gi % world != rank:
                     continue
                 batch_idx = gi // world
-                eng.set_batch(notes, numeric, latent, emot)
+                batch.stage(eng)           # one gather launch from the resident arrays into the engine's buffers
                 g_step = (batch_idx + 1) % critic_iters == 0
                 dp.step(use_graph, g_step)
                 sums[0:1] += eng.loss_d_out[0:1]

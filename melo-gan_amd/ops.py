@@ -574,6 +574,29 @@ def copy_cols(src, soff, dst, doff, ncols, accumulate=False):
                                   1 if accumulate else 0, _stream()), "mg_copy_cols")
 
 
+def stage_rows(jobs, n_rows):
+    """Batch staging in ONE launch: for every (src, dst, idx) in `jobs`, dst[r] = src[idx[r] if idx is not None else r]
+    for r < n_rows.  src/dst: contiguous device tensors of one dtype whose rows (dim 0) have equal byte size; idx: int64
+    device tensor of n_rows entries (clamped into the source on the device)."""
+    if not 0 < len(jobs) <= L.MAX_STAGE_JOBS:
+        raise ValueError(f"stage_rows: 1..{L.MAX_STAGE_JOBS} jobs")
+    arr = (L.StageJob * len(jobs))()
+    for a, (src, dst, idx) in zip(arr, jobs):
+        for nm, t in (("src", src), ("dst", dst)):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous() or t.dim() < 1:
+                raise ValueError(f"stage_rows: {nm} must be a contiguous device tensor")
+        if src.dtype != dst.dtype or src.shape[1:] != dst.shape[1:] or dst.shape[0] < n_rows:
+            raise ValueError(f"stage_rows: row mismatch {tuple(src.shape)} {src.dtype} -> {tuple(dst.shape)} {dst.dtype}")
+        if idx is not None:
+            _chk(idx, "idx", (n_rows,), torch.int64)
+        elif src.shape[0] < n_rows:
+            raise ValueError("stage_rows: source has fewer rows than the batch")
+        row_bytes = src.element_size() * (src[0].numel() if src.dim() > 1 else 1)
+        a.src, a.dst, a.idx = src.data_ptr(), dst.data_ptr(), (None if idx is None else idx.data_ptr())
+        a.row_bytes, a.src_rows = row_bytes, src.shape[0]
+    L.check(L.load().mg_stage_rows(arr, len(jobs), n_rows, _stream()), "mg_stage_rows")
+
+
 def transpose_bcl_blc(x, y):
     """y[b, l, c] = x[b, c, l]."""
     _chk(x, "x")

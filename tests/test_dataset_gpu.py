@@ -24,3 +24,59 @@ def test_streamed_batches_equal_resident_batches():
                 assert torch.equal(xa, xb) and torch.equal(na, nb) and torch.equal(la, lb) and torch.equal(ea, eb)
                 n += 1
         assert n == 203 // 16
+
+
+def test_stage_rows_gathers_and_copies_in_one_launch():
+    """mg_stage_rows against torch.index_select: 16-byte rows, 4-byte rows (int64 labels, odd widths), an unindexed
+    job, a misaligned source view, and out-of-range indices (clamped, never read outside the source)."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    g = torch.Generator().manual_seed(0)
+    notes = torch.rand(37, 8, 12, generator=g).cuda()
+    odd = torch.rand(38, 7, generator=g).cuda()[1:]                 # rows of 28 bytes starting 28 bytes into the allocation
+    lab = torch.randint(0, 4, (37,), generator=g).cuda()
+    dense = torch.rand(16, 5, generator=g).cuda()
+    idx = torch.randint(0, 37, (16,), generator=g).cuda()
+    out = [torch.full((16, 8, 12), -1.0).cuda(), torch.full((16, 7), -1.0).cuda(), torch.full((16,), -1).cuda(),
+           torch.full((20, 5), -1.0).cuda()]
+    ops.stage_rows([(notes, out[0], idx), (odd, out[1], idx), (lab, out[2], idx), (dense, out[3], None)], 16)
+    assert torch.equal(out[0], notes.index_select(0, idx)) and torch.equal(out[1], odd.index_select(0, idx))
+    assert torch.equal(out[2], lab.index_select(0, idx))
+    assert torch.equal(out[3][:16], dense) and bool((out[3][16:] == -1).all())
+    bad = idx.clone()
+    bad[0], bad[1] = -5, 10 ** 12
+    ops.stage_rows([(notes, out[0], bad)], 16)
+    assert torch.equal(out[0][0], notes[0]) and torch.equal(out[0][1], notes[36]) and torch.equal(out[0][2:], notes[idx[2:]])
+    with pytest.raises(ValueError):
+        ops.stage_rows([(notes, out[1], idx)], 16)                  # row shapes differ
+    with pytest.raises(ValueError):
+        ops.stage_rows([(dense, out[3], None)], 20)                 # unindexed source shorter than the batch
+
+
+def test_batch_stage_fills_the_engine_like_set_batch():
+    """Batch.stage (one gather launch from the resident arrays) leaves the engine's inputs exactly as set_batch on the
+    four gathered tensors does, in both dataset modes."""
+    import melo_gan_amd  # noqa: F401
+    from oracle import melo_oracle as O
+    from melo_gan_amd.gan.dataset import GANDataset
+    from melo_gan_amd.gan.engine import GanEngine
+    B, T, Cn = 8, 32, 4
+    cfg = O.default_gan_cfg(B, T, Cn)
+    LAT = cfg["LATENT_DIM"]
+    eng = GanEngine(cfg, O.default_ed_cfg(Cn), "cuda", B)
+    for resident in (True, False):
+        ds = GANDataset.synthetic(50, T, Cn, LAT, seed=2, resident=resident)
+        seen = 0
+        for batch in ds.batches(B, torch.Generator().manual_seed(1)):
+            notes, numeric, latent, emot = batch.tensors()
+            for t in (eng.X0, eng.numeric, eng.latent):
+                t.fill_(float("nan"))
+            eng.emot_idx.fill_(-1)
+            batch.stage(eng)
+            got = [eng.X0[:B].clone(), eng.numeric.clone(), eng.latent.clone(), eng.emot_idx.clone()]
+            eng.set_batch(notes.cpu(), numeric.cpu(), latent.cpu(), emot.cpu())          # host sources: torch copies
+            want = [eng.X0[:B], eng.numeric, eng.latent, eng.emot_idx]
+            assert all(torch.equal(a, b) for a, b in zip(got, want))
+            assert torch.equal(got[0], notes) and torch.equal(got[3], emot)
+            seen += 1
+        assert seen == 50 // B
