@@ -198,6 +198,9 @@ class GanEngine:
         self.num_batches_tracked = 0
         self.ed_scale = [torch.empty(co, device=d) for (_, co, _) in self.ed_chans]
         self.ed_shift = [torch.empty(co, device=d) for (_, co, _) in self.ed_chans]
+        # the frozen ED's conv weights re-laid once as (Cin, Cout, K): its forward then takes the window GEMM's CNK
+        # weight staging (coalesced dword loads + conflict-free 16-B LDS stores), 5-7 % faster than the NCK one
+        self.ed_wt = [torch.empty(ci, co, k, device=d) for (ci, co, k) in self.ed_chans]
 
         # ---- static inputs ----
         z = lambda *s: torch.zeros(*s, device=d)  # noqa: E731
@@ -453,6 +456,7 @@ class GanEngine:
             pre = f"encoder.conv.{i}.net"
             ops.bn_fold(self.ED.p[pre + ".1.weight"], self.ED.p[pre + ".1.bias"], self.EDbuf[pre + ".1.running_mean"],
                         self.EDbuf[pre + ".1.running_var"], self.ED.p[pre + ".0.bias"], self.ed_scale[i], self.ed_shift[i], BN_EPS)
+            self.ed_wt[i].copy_(self.ED.p[pre + ".0.weight"].permute(1, 0, 2))
         self._ed_folded = True
 
     def _ed_fwd(self, notes: Tensor):
@@ -461,8 +465,9 @@ class GanEngine:
         if self.ed_mode == "notes":
             x = notes
             for i in range(len(self.ed_chans)):
-                ops.conv1d_fwd(x, P[f"encoder.conv.{i}.net.0.weight"], self.ed_a[i], 1, scale=self.ed_scale[i],
-                               shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+                ci, co, k = self.ed_chans[i]
+                ops.conv_gather(x, self.ed_wt[i], self.ed_a[i], co, k, 1, k, co * k, scale=self.ed_scale[i],
+                                shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
                 x = self.ed_a[i]
             ops.meanT_fwd(x, self.ed_pool)
             ops.linear_fwd(self.ed_pool, P["encoder.project.weight"], self.ed_proj, bias=P["encoder.project.bias"])
