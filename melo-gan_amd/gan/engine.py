@@ -627,23 +627,19 @@ class GanEngine:
             acc = False
         self._join()
         ops.conv1d_dgrad(self.dZ1[:B], self.D.p["conv.0.weight"], self.dnotes, 2, accumulate=acc)
-        # ---- generator backward: data-gradient chain on this stream, weight/bias gradients on side streams ----
+        # ---- generator backward: the data-gradient chain down to decoder.pre.2, then pre.2's weight gradient -- 89 % of
+        # the generator's gradient bytes, all-reduced while g_backward_b runs.  The deconvolutions' weight gradients
+        # are not on that chain and wait in g_backward_b, where they widen the window the all-reduce hides in. ----
         dn = self.dnotes
         if self.dn_dense is not None:      # zero-padded tail rows carry no gradient (models.py:78-81)
             ops.copy_cols(self.dnotes.view(B, -1), 0, self.dn_dense.view(B, -1), 0, self.L3 * self.C)
             dn = self.dn_dense
-        with self._branch(0):
-            ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"))
         ops.convT1d_dgrad(dn, PG("decoder.deconv.6.weight"), self.d_ad3)
         ops.bn_train_bwd(self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, PG("decoder.deconv.4.weight"), self.bn_mean[1],
                          self.bn_invstd[1], GG("decoder.deconv.4.weight"), GG("decoder.deconv.4.bias"), ACT_RELU)
-        with self._branch(1):
-            ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"))
         ops.convT1d_dgrad(self.d_zd3, PG("decoder.deconv.3.weight"), self.d_ad0)
         ops.bn_train_bwd(self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, PG("decoder.deconv.1.weight"), self.bn_mean[0],
                          self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
-        with self._branch(0):
-            ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"))
         ops.convT1d_dgrad(self.d_zd0, PG("decoder.deconv.0.weight"), self.d_y0)
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
@@ -655,6 +651,14 @@ class GanEngine:
         B = self.B
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         PE, GEg = self._ep, (lambda k: self.GE.g["E." + k])
+        # the deconvolutions' weight / bias gradients (inputs and output gradients were kept by g_backward_a2)
+        dn = self.dn_dense if self.dn_dense is not None else self.dnotes
+        with self._branch(0):
+            ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"))
+        with self._branch(1):
+            ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"))
+        with self._branch(0):
+            ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
         with self._branch(0, small=True):
             ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"))
