@@ -250,7 +250,12 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # MELO_FORCE_DP=1 (rehearsal, never set by the driver): a 1-rank RCCL group and the N > 1 step order on one GPU
+    force_dp = os.environ.get("MELO_FORCE_DP") == "1" and world == 1
+    if force_dp:
+        os.environ.setdefault("MASTER_PORT", "29577")
+    dist_on = world > 1 or force_dp
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -267,7 +272,7 @@ def main():
     cfg, ed_cfg = default_gan_cfg(B_PER_GPU, T, C), default_ed_cfg(C)
     eng = GanEngine(cfg, ed_cfg, f"cuda:{local_rank}", B_PER_GPU)
     eng.init_weights(seed=42)                       # identical on every rank
-    dp = DataParallel(eng, world, dist if world > 1 else None)
+    dp = DataParallel(eng, world, dist if dist_on else None, force_collectives=force_dp)
     dp.broadcast_params()
     # synthetic data resident in HBM: a small pool of per-rank batches (SURVEY 8d recipe)
     g = torch.Generator().manual_seed(42 + 1000 * rank)
@@ -286,8 +291,9 @@ def main():
         dp.step(use_graph)        # melo-gan_amd/gan/dp.py: the graphs of one step and, for N > 1, the overlapped all-reduces
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if dist_on:
+            # this script's own collectives stay off the engine's stream (async_op + wait): see ops._quiesce_process_group
+            dist.barrier(async_op=True).wait()
 
     with torch.cuda.stream(eng.stream):
         for i in range(max(args.warmup, 3 if use_graph else 1)):
@@ -302,9 +308,9 @@ def main():
         barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             t = torch.tensor([el], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True).wait()
             el = float(t.item())
 
         # ---- secondary: the reference's schedule, CRITIC_ITERS = 5 critic updates per generator update ----
@@ -325,9 +331,9 @@ def main():
             barrier()
             torch.cuda.synchronize()
             el5 = time.perf_counter() - t0
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([el5], device="cuda", dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True).wait()
                 el5 = float(t.item())
             sched = {"metric": "samples/s at the reference schedule (5 critic updates : 1 generator update)",
                      "value": round(world * B_PER_GPU * iters * 5 / el5, 1), "batches": iters * 5,
@@ -370,8 +376,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds)
-    if world > 1:
-        dist.barrier()
+    if dist_on:
+        dist.barrier(async_op=True).wait()
         dist.destroy_process_group()
     if rank == 0:
         value = world * B_PER_GPU * args.steps / el

@@ -279,6 +279,7 @@ class GanEngine:
         self.side = [torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)]
         self.branch_mode = os.environ.get("MELO_BRANCH", "none")
         self.world_size = 1
+        self.p2_world = 0          # > 0: decoder.pre.2's weight gradient comes from all-gathered factors (enable_p2_gather)
         self._ed_folded = False
 
     # -------------------------------------------------------------------------------------
@@ -644,7 +645,12 @@ class GanEngine:
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
         ops.act_bwd(self.d_p2, self.d_p2, gref=self.a_p2, gact=ACT_RELU)
-        ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"))
+        if self.p2_world:
+            # data parallel, factor gather: only the bias gradient here (it travels with the small all-reduce); the
+            # weight gradient is computed by g_backward_p2b from every rank's (d_p2, a_p0)
+            ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
+        else:
+            ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"))
         self._join()
 
     def g_backward_b(self):
@@ -684,6 +690,21 @@ class GanEngine:
         ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
         ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
         self._join()
+
+    def enable_p2_gather(self, world: int):
+        """Data parallelism without all-reducing decoder.pre.2.weight's gradient (16.8 of the 18.8 MB at cfg2): that
+        gradient is d_p2^T a_p0, a product of two per-sample factors of (B, 256 red) and (B, 512) floats -- 2.2 MB per
+        rank.  The ranks all-gather the factors into d_p2_all / a_p0_all and every rank computes the GLOBAL batch's
+        weight gradient itself (the same sum an all-reduce would deliver, `world` times the rows in one wgrad launch)."""
+        self.p2_world = int(world)
+        self.d_p2_all = torch.zeros(self.p2_world * self.B, 256 * self.red, device=self.dev)
+        self.a_p0_all = torch.zeros(self.p2_world * self.B, 512, device=self.dev)
+
+    def g_backward_p2b(self):
+        """Second half of the G-step backward under enable_p2_gather: pre.2's global weight gradient from the gathered
+        factors, then everything g_backward_b does."""
+        ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"])
+        self.g_backward_b()
 
     def g_update(self):
         self._adam(self.GE, self.lr_g)
@@ -730,7 +751,8 @@ class GanEngine:
             self._graphs[name] = g
             st = g
         st.launch()
-        if name in ("d_backward", "g_backward", "d_backward_rng", "g_backward_rng", "g_backward_a", "g_backward_a_rng"):
+        if name in ("d_backward", "g_backward", "d_backward_rng", "g_backward_rng", "g_backward_a", "g_backward_a_rng",
+                    "g_forward", "g_forward_rng"):
             self.num_batches_tracked += 1
 
     # -------------------------------------------------------------------------------------

@@ -156,7 +156,7 @@ def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: 
         save_checkpoint(eng, os.path.join(cfg["CHECKPOINT_DIR"], "gan_final.pth"), full=False)
         writer.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier(async_op=True).wait()
         dist.destroy_process_group()
     log("Training Complete.")
     return eng

@@ -1,0 +1,64 @@
+"""Data-parallel "gather" mode on the GPU engine (melo-gan_amd/gan/dp.py): decoder.pre.2.weight's gradient computed from
+the all-gathered per-sample factors equals the sum of the shards' own weight gradients -- what an all-reduce delivers.
+Two engines in one process stand in for two ranks; the collectives are done by hand."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import melo_oracle as O  # noqa: E402
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def test_factor_gather_equals_summed_shard_gradients():
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.gan.engine import GanEngine
+    B, T, C, WORLD = 4, 32, 4, 2
+    cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
+    engs = [GanEngine(cfg, ed_cfg, "cuda", B) for _ in range(WORLD)]
+    inputs = []
+    for r, e in enumerate(engs):
+        e.init_weights(seed=3)                       # identical replicas
+        g = torch.Generator().manual_seed(50 + r)    # each rank its own shard and its own draws
+        real, numeric, latent, emot = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 70 + r)
+        noise = torch.randn(tuple(e.noise.shape), generator=g)
+        masks = [(torch.rand(tuple(m.shape), generator=g) < 0.8).float() for m in e.dmask]
+        inputs.append((real.cuda(), numeric.cuda(), latent.cuda(), emot.cuda(), noise.cuda(), [m.cuda() for m in masks]))
+    assert torch.equal(engs[0].GE.data, engs[1].GE.data)
+
+    def feed(e, x):
+        e.set_batch(*x[:4])
+        e.set_randoms(x[4], x[5])
+
+    # the shards' own gradients (single-GPU path), summed = what all-reduce(SUM) hands every rank
+    ref = []
+    for e, x in zip(engs, inputs):
+        feed(e, x)
+        e.g_backward()
+        ref.append(e.GE.grad.clone())
+    want = ref[0] + ref[1]
+    off, n = engs[0].big_grad_slice()
+    assert off == 0 and n == 256 * engs[0].red * 512
+
+    # gather mode
+    for e, x in zip(engs, inputs):
+        e.enable_p2_gather(WORLD)
+        e.GE.grad.fill_(float("nan"))
+        feed(e, x)
+        e.g_backward_a()
+    d_all = torch.cat([e.d_p2 for e in engs])        # all_gather_into_tensor: rank order
+    a_all = torch.cat([e.a_p0 for e in engs])
+    for e in engs:
+        e.d_p2_all.copy_(d_all)
+        e.a_p0_all.copy_(a_all)
+        e.g_backward_p2b()
+    assert not torch.isnan(engs[0].GE.grad).any()
+    assert torch.equal(engs[0].GE.grad[:n], engs[1].GE.grad[:n])            # every rank holds the same global gradient
+    assert rel_err(engs[0].GE.grad[:n], want[:n]) < 2e-6
+    rest = engs[0].GE.grad[n:] + engs[1].GE.grad[n:]                         # the remaining all-reduce
+    assert rel_err(rest, want[n:]) < 2e-6
+    o, m = engs[0].GE.offsets["G.decoder.pre.2.bias"]
+    assert o >= n and rel_err(rest[o - n:o - n + m], want[o:o + m]) < 2e-6   # bias: local column sums, then all-reduced
