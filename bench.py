@@ -77,23 +77,26 @@ class RecordHook:
 
 
 def time_dominant(ops, records, reps):
-    """HIP-event time of `reps` replays of the recorded launches (same tensors, same order as in the step), issued
-    back to back from one hipGraph on the launch stream: per-launch duration without host launch gaps."""
-    g = ops.Graph()
-    g.begin()
+    """Summed duration (ms) of `reps` replays of the recorded launches (same tensors, same order as in the step), each
+    launch between its OWN pair of HIP events on the launch stream: one dispatch at a time, which is what rocprofv3's
+    kernel trace reports too.  (Back-to-back replay from one hipGraph under a single event pair lets a launch's ramp
+    overlap its predecessor's drain and read ~5 % shorter than the kernel takes inside the step.)"""
+    for _, _, launch in records:                 # warm
+        if launch() != 0:
+            raise RuntimeError("replayed launch failed")
+    pairs = [(ops.Event(), ops.Event()) for _ in range(reps * len(records))]
+    i = 0
     for _ in range(reps):
         for _, _, launch in records:
+            a, b = pairs[i]
+            i += 1
+            a.record()
             rc = launch()
+            b.record()
             if rc != 0:
                 raise RuntimeError(f"replayed launch failed: rc={rc}")
-    g.end()
-    g.launch()                                   # warm
-    e0, e1 = ops.Event(), ops.Event()
-    e0.record()
-    g.launch()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_ms(e1)
+    return sum(a.elapsed_ms(b) for a, b in pairs)
 
 
 def host_cores() -> int:
