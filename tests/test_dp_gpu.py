@@ -62,3 +62,16 @@ def test_factor_gather_equals_summed_shard_gradients():
     assert rel_err(rest, want[n:]) < 2e-6
     o, m = engs[0].GE.offsets["G.decoder.pre.2.bias"]
     assert o >= n and rel_err(rest[o - n:o - n + m], want[o:o + m]) < 2e-6   # bias: local column sums, then all-reduced
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_trainer_gather_equals_allreduce(tmp_path):
+    """The trainer CLI under torch.distributed.run with 2 ranks (sharing this GPU, gloo): one epoch in MELO_DP_MODE=gather
+    and in =allreduce from the same seed ends in the same generator / encoder parameters (tools/dp_mode_equivalence.sh)."""
+    import os
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "dp_mode_equivalence.sh"), str(tmp_path)], cwd=root,
+                       capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "largest relative difference gather vs allreduce" in r.stdout
