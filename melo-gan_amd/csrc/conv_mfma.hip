@@ -66,7 +66,8 @@ template <int K> struct ChunkOf { static constexpr int value = (K == 1) ? 64 : 1
 // LDS images (one chunk = BKC channels):
 //   window  Xs[row][SX]            SX = BKC + 4 floats: 16-B aligned rows whose pitch is an odd number of
 //                                  16-B granules, so the 16 lanes of a ds_read_b128 group hit 16 bank quads
-//   weights Ws[tap][quad][n][4]    quad = channel/4: the 4 channels of a quad are contiguous per output column
+//   weights Ws[plane][n][4]        one plane per (quad = channel/4, tap): the 4 channels of a quad are contiguous
+//                                  per output column; plane order and pitch depend on the weight layout (below)
 // Every MFMA operand is read with ds_read_b128: lane (i, h = lane>>5) takes channel quad 2g+h of its row /
 // column, which feeds the 4 MFMAs s = 0..3 of channel group g (MFMA k-slot h <-> channel 8g + 4h + s on both
 // operands).  One 16-B read per 4 MFMAs instead of one 4-B read per MFMA: with a single wave per SIMD the 4-B
