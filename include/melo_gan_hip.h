@@ -125,6 +125,20 @@ int mg_wgrad(const float* s0, const float* l0, int nb0,
              float* out, float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride,
              void* work, size_t work_bytes, mg_stream_t stream);
 
+/* Several independent weight gradients of ONE (K, stride) in one launch (+ one reduce launch if any of them is split):
+ * the small layers' gradients are each a few workgroups at the launch floor.  Each job has the meaning of one
+ * mg_wgrad call; `work` must hold the SUM over jobs of mg_wgrad_workspace_bytes(A, Bc, K, nb0 + nb1, Ts), each rounded
+ * up to 256 bytes.  Outputs of different jobs must not overlap. */
+#define MG_MAX_WGRAD_JOBS 8
+typedef struct mg_wgrad_job {
+    const float* s0; const float* l0; int nb0;
+    const float* s1; const float* l1; int nb1;
+    float* out; float* bias_out; int bias_from;
+    int Ts, Tl, A, Bc;
+} mg_wgrad_job;
+int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int stride, void* work, size_t work_bytes,
+                   mg_stream_t stream);
+
 /* ---- per-channel column reductions over rows of a (R, C) matrix ----
  * sum[c] = sum_r x[r,c] (and sumsq if sumsq != NULL).  Used for bias gradients and BN statistics.
  * `work`: mg_colsum_workspace_bytes(C). */

@@ -22,6 +22,14 @@ class StageJob(C.Structure):
 
 MAX_STAGE_JOBS = 8
 
+
+class WgradJob(C.Structure):
+    _fields_ = [("s0", vp), ("l0", vp), ("nb0", i32), ("s1", vp), ("l1", vp), ("nb1", i32),
+                ("out", vp), ("bias_out", vp), ("bias_from", i32), ("Ts", i32), ("Tl", i32), ("A", i32), ("Bc", i32)]
+
+
+MAX_WGRAD_JOBS = 8
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
 SIGNATURES = {
     "mg_version": (i32, []),
@@ -34,6 +42,7 @@ SIGNATURES = {
     "mg_conv_tile_config": (i32, [i64, i32, i32]),
     "mg_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "mg_wgrad": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "mg_wgrad_multi": (i32, [vp, i32, i32, i32, vp, sz, vp]),
     "mg_colsum_workspace_bytes": (sz, [i32]),
     "mg_colsum": (i32, [vp, i64, i32, vp, vp, vp, sz, vp]),
     "mg_bn_workspace_bytes": (sz, [i32]),

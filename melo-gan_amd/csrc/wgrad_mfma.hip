@@ -58,8 +58,9 @@ __device__ long long* mg_wstamp_buf = nullptr;
 #define MG_STAMP(k)
 #endif
 
+// One workgroup's work: output tile (bx, by) of slice bz of the weight gradient described by p.
 template <int S, int K>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
+__device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const int by, const int bz) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int RMAX = (RT - 1) * S + K;                 // L-window rows when one batch fills the chunk
     constexpr int NS4 = RT * (BA / 4) / 256;               // float4 prefetch slots for S  (= 2)
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     const int lrows = TB * R;
     float* Ss = smem;                    // [RT][BA]
     float* Ls = smem + RT * BA;          // [TB*R][BB]
-    const int a0 = blockIdx.x * BA, b0 = blockIdx.y * BB;
-    const int split = blockIdx.z;
+    const int a0 = bx * BA, b0 = by * BB;
+    const int split = bz;
 
     f32x16 acc[K];
 #pragma unroll
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
 
     // bias gradient fused in: per chunk every thread adds its share of the staged rows' column sums
     float bsum = 0.f;
-    const bool do_bias_s = p.bias_from == 1 && blockIdx.y == 0;
-    const bool do_bias_l = p.bias_from == 2 && blockIdx.x == 0;
+    const bool do_bias_s = p.bias_from == 1 && by == 0;
+    const bool do_bias_l = p.bias_from == 2 && bx == 0;
     auto bias_accum_at = [&](int boff, int seg_id) {
         if (seg_id >= p.nseg_bias) return;
         const int cx = tid & 31, rq = tid >> 5;      // 32 channels x 8 row lanes
@@ -423,6 +424,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     MG_STAMP(3);
 }
 
+template <int S, int K>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
+    wgrad_body<S, K>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent weight gradients of one (stride, K) in ONE launch: the small layers' gradients are each a
+// handful of workgroups at the launch floor (~4.7 us per launch and dependent boundary), together they fill the chip
+// once.  Workgroups are numbered job by job; first[j] is job j's first workgroup.
+struct WgradJobs {
+    WgradP p[MG_MAX_WGRAD_JOBS];
+    int first[MG_MAX_WGRAD_JOBS + 1];
+    int gx[MG_MAX_WGRAD_JOBS], gy[MG_MAX_WGRAD_JOBS];
+    int n;
+};
+template <int S, int K>
+__global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgradJobs J) {
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;       // uniform
+    const int b = (int)blockIdx.x - J.first[j];
+    const int gx = J.gx[j], gxy = gx * J.gy[j];
+    const int bz = b / gxy, r = b - bz * gxy;
+    const WgradP p = J.p[j];
+    wgrad_body<S, K>(p, r % gx, r / gx, bz);
+}
+
 // out[i] = sum_z part[z][i]; 64 elements x 4 slice-groups per block (fixed summation order => reproducible).
 // Elements [0, wn) go to `out` (weight gradient), elements [wn, n) to `bias_out`.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -439,6 +465,37 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         const float v = (sh[0][ex] + sh[1][ex]) + (sh[2][ex] + sh[3][ex]);
         if (i < wn) out[i] = v;
         else bias_out[i - wn] = v;
+    }
+}
+
+struct ReduceJobs {
+    const float* part[MG_MAX_WGRAD_JOBS];
+    float* out[MG_MAX_WGRAD_JOBS];
+    float* bias_out[MG_MAX_WGRAD_JOBS];
+    long n[MG_MAX_WGRAD_JOBS], wn[MG_MAX_WGRAD_JOBS];
+    int nsplit[MG_MAX_WGRAD_JOBS];
+    int first[MG_MAX_WGRAD_JOBS + 1];
+    int njobs;
+};
+// reduce_slabs_kernel for the split jobs of a multi launch (same summation order per element)
+__global__ __launch_bounds__(256) void reduce_slabs_multi_kernel(const ReduceJobs J) {
+    __shared__ float sh[4][64];
+    int j = 0;
+    while (j + 1 < J.njobs && (int)blockIdx.x >= J.first[j + 1]) ++j;
+    const float* __restrict__ part = J.part[j];
+    const long n = J.n[j], wn = J.wn[j];
+    const int nsplit = J.nsplit[j];
+    const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)((int)blockIdx.x - J.first[j]) * 64 + ex;
+    float s = 0.f;
+    if (i < n)
+        for (int z = g; z < nsplit; z += 4) s += part[(long)z * n + i];
+    sh[g][ex] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        const float v = (sh[0][ex] + sh[1][ex]) + (sh[2][ex] + sh[3][ex]);
+        if (i < wn) J.out[j][i] = v;
+        else J.bias_out[j][i - wn] = v;
     }
 }
 
@@ -496,9 +553,12 @@ extern "C" size_t mg_wgrad_workspace_bytes(int A, int Bc, int K, int nb_total, i
     return (size_t)ns * ((size_t)A * (size_t)Bc * (size_t)K + (size_t)(A > Bc ? A : Bc)) * sizeof(float);
 }
 
-extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* s1, const float* l1, int nb1,
-                        float* out, float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride,
-                        void* work, size_t work_bytes, mg_stream_t stream) {
+namespace {
+// Validates one weight-gradient description and fills the kernel parameters, the LDS request and the grid.
+// `work` is where THIS job's partial slabs go (used only when the plan splits).
+int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, const float* l1, int nb1, float* out,
+                float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride, void* work,
+                size_t work_bytes, WgradP& p, Plan& pl, size_t& lds, dim3& grid) {
     MG_CHECK_ARG(bias_from >= 0 && bias_from <= 2 && ((bias_from == 0) == (bias_out == nullptr)),
                  "mg_wgrad: bias_out and bias_from (1: sums of S, 2: sums of L) must be given together");
     MG_CHECK_ARG(s0 && l0 && out && nb0 > 0, "mg_wgrad: null/empty segment 0");
@@ -506,14 +566,18 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     MG_CHECK_ARG(Ts > 0 && Tl > 0 && A > 0 && Bc > 0, "mg_wgrad: bad shape");
     MG_CHECK_ARG(K == 1 || K == 3 || K == 5, "mg_wgrad: K=%d unsupported", K);
     MG_CHECK_ARG(stride == 1 || stride == 2, "mg_wgrad: stride=%d unsupported", stride);
-    const Plan pl = make_plan(A, Bc, K, nb0, nb1, Ts);
+    if (stride == 2 && K != 5) {
+        mg_set_error("mg_wgrad: stride 2 needs K=5");
+        return MG_EUNSUP;
+    }
+    pl = make_plan(A, Bc, K, nb0, nb1, Ts);
     const long wslab = (long)A * Bc * K;
     const long slab = wslab + (bias_from == 1 ? A : bias_from == 2 ? Bc : 0);
     if (pl.nsplit > 1 && (!work || work_bytes < (size_t)pl.nsplit * slab * sizeof(float))) {
         mg_set_error("mg_wgrad: workspace too small (%zu < %zu)", work_bytes, (size_t)pl.nsplit * slab * sizeof(float));
         return MG_EWORK;
     }
-    WgradP p{};
+    p = WgradP{};
     p.s[0] = s0; p.l[0] = l0; p.nb[0] = nb0;
     p.s[1] = s1; p.l[1] = l1; p.nb[1] = nb1;
     p.part = pl.nsplit > 1 ? (float*)work : nullptr;     // one slice: no slabs, no reduce launch
@@ -531,27 +595,88 @@ extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* 
     size_t lds_floats = 2 * ((size_t)RT * BA + (size_t)pl.TB * R * BB) + 256 * 4;   // two buffers + the staging sink
     const size_t epi_floats = (size_t)4 * K * 32 * 33;     // the final cross-wave reduction reuses the buffer
     if (lds_floats < epi_floats) lds_floats = epi_floats;
-    const size_t lds = lds_floats * sizeof(float);
-    {
-        auto ok = [](const float* q, long elems) { return q == nullptr || (((((uintptr_t)q) & 15) == 0) && elems * 4 < (1L << 31)); };
-        p.vec_ok = ok(s0, (long)nb0 * Ts * A) && ok(l0, (long)nb0 * Tl * Bc) && ok(nb1 ? s1 : nullptr, (long)nb1 * Ts * A) &&
-                   ok(nb1 ? l1 : nullptr, (long)nb1 * Tl * Bc);
-    }
-    dim3 grid((unsigned)mg_cdiv(A, BA), (unsigned)mg_cdiv(Bc, BB), (unsigned)pl.nsplit);
+    lds = lds_floats * sizeof(float);
+    auto ok = [](const float* q, long elems) { return q == nullptr || (((((uintptr_t)q) & 15) == 0) && elems * 4 < (1L << 31)); };
+    p.vec_ok = ok(s0, (long)nb0 * Ts * A) && ok(l0, (long)nb0 * Tl * Bc) && ok(nb1 ? s1 : nullptr, (long)nb1 * Ts * A) &&
+               ok(nb1 ? l1 : nullptr, (long)nb1 * Tl * Bc);
+    grid = dim3((unsigned)mg_cdiv(A, BA), (unsigned)mg_cdiv(Bc, BB), (unsigned)pl.nsplit);
+    return MG_OK;
+}
+}  // namespace
+
+extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* s1, const float* l1, int nb1,
+                        float* out, float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride,
+                        void* work, size_t work_bytes, mg_stream_t stream) {
+    WgradP p;
+    Plan pl;
+    size_t lds;
+    dim3 grid;
+    const int rc = build_wgrad(s0, l0, nb0, s1, l1, nb1, out, bias_out, bias_from, Ts, Tl, A, Bc, K, stride, work,
+                               work_bytes, p, pl, lds, grid);
+    if (rc != MG_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
 #define MG_WG(S_, K_) hipLaunchKernelGGL((wgrad_kernel<S_, K_>), grid, dim3(256), lds, st, p)
     if (stride == 1) {
         if (K == 1) MG_WG(1, 1); else if (K == 3) MG_WG(1, 3); else MG_WG(1, 5);
     } else {
-        if (K == 5) MG_WG(2, 5);
-        else { mg_set_error("mg_wgrad: stride 2 needs K=5"); return MG_EUNSUP; }
+        MG_WG(2, 5);
     }
 #undef MG_WG
     MG_CHECK_LAUNCH("wgrad_kernel");
     if (pl.nsplit > 1) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(slab, 64)), dim3(256), 0, st,
-                           (const float*)work, out, bias_out, slab, wslab, pl.nsplit);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(p.slab, 64)), dim3(256), 0, st,
+                           (const float*)work, out, bias_out, p.slab, p.wslab, pl.nsplit);
         MG_CHECK_LAUNCH("reduce_slabs_kernel");
+    }
+    return MG_OK;
+}
+
+extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int stride, void* work, size_t work_bytes,
+                              mg_stream_t stream) {
+    MG_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= MG_MAX_WGRAD_JOBS, "mg_wgrad_multi: 1..%d jobs", MG_MAX_WGRAD_JOBS);
+    WgradJobs J{};
+    ReduceJobs Rj{};
+    size_t lds_max = 0, used = 0;
+    int nblocks = 0, rblocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const mg_wgrad_job& q = jobs[i];
+        Plan pl;
+        size_t lds;
+        dim3 grid;
+        // every job's slabs get their own 256-byte aligned piece of the workspace
+        const size_t need = mg_wgrad_workspace_bytes(q.A, q.Bc, K, q.nb0 + q.nb1, q.Ts);
+        void* w = used < work_bytes && work ? (char*)work + used : nullptr;
+        const int rc = build_wgrad(q.s0, q.l0, q.nb0, q.s1, q.l1, q.nb1, q.out, q.bias_out, q.bias_from, q.Ts, q.Tl, q.A,
+                                   q.Bc, K, stride, w, w ? work_bytes - used : 0, J.p[i], pl, lds, grid);
+        if (rc != MG_OK) return rc;
+        if (pl.nsplit > 1) {
+            used += (need + 255) & ~(size_t)255;
+            const int r = Rj.njobs++;
+            Rj.part[r] = J.p[i].part; Rj.out[r] = q.out; Rj.bias_out[r] = q.bias_out;
+            Rj.n[r] = J.p[i].slab; Rj.wn[r] = J.p[i].wslab; Rj.nsplit[r] = pl.nsplit;
+            Rj.first[r] = rblocks;
+            rblocks += (int)mg_cdiv(J.p[i].slab, 64);
+        }
+        lds_max = lds > lds_max ? lds : lds_max;
+        J.first[i] = nblocks;
+        J.gx[i] = (int)grid.x; J.gy[i] = (int)grid.y;
+        nblocks += (int)(grid.x * grid.y * grid.z);
+    }
+    J.first[n_jobs] = nblocks;
+    J.n = n_jobs;
+    Rj.first[Rj.njobs] = rblocks;
+    hipStream_t st = (hipStream_t)stream;
+#define MG_WG(S_, K_) hipLaunchKernelGGL((wgrad_multi_kernel<S_, K_>), dim3((unsigned)nblocks), dim3(256), lds_max, st, J)
+    if (stride == 1) {
+        if (K == 1) MG_WG(1, 1); else if (K == 3) MG_WG(1, 3); else MG_WG(1, 5);
+    } else {
+        MG_WG(2, 5);
+    }
+#undef MG_WG
+    MG_CHECK_LAUNCH("wgrad_multi_kernel");
+    if (Rj.njobs > 0) {
+        hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, Rj);
+        MG_CHECK_LAUNCH("reduce_slabs_multi_kernel");
     }
     return MG_OK;
 }

@@ -540,17 +540,18 @@ class GanEngine:
         # Weight gradients are [real,fake] activations x Wasserstein dZ + tangent activations x penalty dZ; each
         # becomes launchable as soon as its tangent exists, so they run on side streams next to the tangent pass
         # (d(lambda*gp)/d(grad_xhat) pushed forward through the masked linear critic).
-        with self._branch(0):
-            ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:],
-                             db=G["conv.0.bias"])
         ops.conv1d_fwd(self.TAN0, P["conv.0.weight"], self.TAN1, 2, gref=self.A1[2 * B:], gact=ACT_LRELU)
-        with self._branch(1):
-            ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:],
-                             db=G["conv.2.bias"])
         ops.conv1d_fwd(self.TAN1, P["conv.2.weight"], self.TAN2, 2, gref=self.A2[2 * B:], gact=ACT_LRELU)
         ops.conv1d_fwd(self.TAN2, P["conv.4.weight"], self.TZ3, 2, gref=self.A3[2 * B:], gact=ACT_LRELU)
-        ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:],
-                         db=G["conv.4.bias"])
+        # the three convolutions' weight gradients go out as ONE launch (+ one slab reduction) once their tangents
+        # exist (ops.wgrad_multi): three launches of ~256 workgroups each plus three reductions before
+        ops.wgrad_multi([
+            ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:],
+                             db=G["conv.0.bias"], defer=True),
+            ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:],
+                             db=G["conv.2.bias"], defer=True),
+            ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:],
+                             db=G["conv.4.bias"], defer=True)])
         ops.meanT_fwd(self.TZ3, self.ghb)
         ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[2 * B:], gact=ACT_LRELU)
         ops.linear_wgrad(self.H[:2 * B], self.dU[:2 * B], G["fc.1.weight"], self.ghb, self.dU[2 * B:], db=G["fc.1.bias"])
@@ -653,43 +654,41 @@ class GanEngine:
             ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"))
         self._join()
 
-    def g_backward_b(self):
+    def g_backward_b(self, extra_jobs=()):
         B = self.B
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         PE, GEg = self._ep, (lambda k: self.GE.g["E." + k])
-        # the deconvolutions' weight / bias gradients (inputs and output gradients were kept by g_backward_a2)
+        # Weight / bias gradients are collected and go out at the end as one launch per kernel shape (ops.wgrad_multi):
+        # the three deconvolutions (their inputs and output gradients were kept by g_backward_a2) and the six small
+        # Linear layers, 12 launches at the launch floor before.
         dn = self.dn_dense if self.dn_dense is not None else self.dnotes
-        with self._branch(0):
-            ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"))
-        with self._branch(1):
-            ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"))
-        with self._branch(0):
-            ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"))
+        jobs = list(extra_jobs)
+        jobs.append(ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"), defer=True))
+        jobs.append(ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"),
+                                      defer=True))
+        jobs.append(ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"),
+                                      defer=True))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
-        with self._branch(0, small=True):
-            ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"))
+        jobs.append(ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"), defer=True))
         ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
         if self.ed_mode != "notes":
             ops.axpby(self.ed_dfeat, self.d_lat, 1.0, 1.0)
-        with self._branch(1, small=True):
-            ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"), db=GG("noise_to_latent.net.2.bias"))
+        jobs.append(ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"),
+                                     db=GG("noise_to_latent.net.2.bias"), defer=True))
         ops.linear_dgrad(self.d_lat, PG("noise_to_latent.net.2.weight"), self.d_n0, gref=self.a_n0, gact=ACT_RELU)
-        with self._branch(0, small=True):
-            ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"), db=GG("noise_to_latent.net.0.bias"))
+        jobs.append(ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"),
+                                     db=GG("noise_to_latent.net.0.bias"), defer=True))
         ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
         # embedding gradient = generator-input slice + critic-head path, then E_num backward
         ops.copy_cols(self.d_gin, self.noise_dim, self.demb, 0, self.E, accumulate=True)
-        with self._branch(1, small=True):
-            ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"), db=GEg("net.7.bias"))
+        jobs.append(ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"), db=GEg("net.7.bias"), defer=True))
         ops.linear_dgrad(self.demb, PE("net.7.weight"), self.d_ez2, gref=self.e_z2, gact=ACT_GELU, emul=self.dmask[1])
-        with self._branch(0, small=True):
-            ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"), db=GEg("net.4.bias"))
+        jobs.append(ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"), db=GEg("net.4.bias"), defer=True))
         ops.linear_dgrad(self.d_ez2, PE("net.4.weight"), self.d_ez1, gref=self.e_z1, gact=ACT_GELU, emul=self.dmask[0])
-        with self._branch(1, small=True):
-            ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"), db=GEg("net.1.bias"))
+        jobs.append(ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"), db=GEg("net.1.bias"), defer=True))
         ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
         ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
-        self._join()
+        ops.wgrad_multi(jobs)
 
     def enable_p2_gather(self, world: int):
         """Data parallelism without all-reducing decoder.pre.2.weight's gradient (16.8 of the 18.8 MB at cfg2): that
@@ -703,8 +702,7 @@ class GanEngine:
     def g_backward_p2b(self):
         """Second half of the G-step backward under enable_p2_gather: pre.2's global weight gradient from the gathered
         factors, then everything g_backward_b does."""
-        ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"])
-        self.g_backward_b()
+        self.g_backward_b([ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"], defer=True)])
 
     def g_update(self):
         self._adam(self.GE, self.lr_g)

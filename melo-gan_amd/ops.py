@@ -302,23 +302,85 @@ def wgrad(small: Tensor, large: Tensor, out: Tensor, K: int, stride: int,
     return out
 
 
-def conv1d_wgrad(x, dy, dw, stride, x2=None, dy2=None, db=None):
-    """dw (Cout, Cin, K) for nn.Conv1d: S = dy, L = x; db (Cout) = column sums of dy (segment 0) if given."""
+def _wgrad_job(small, large, out, K, stride, small2=None, large2=None, bias_out=None, bias_from=0):
+    """Argument checks of wgrad(), as a tuple for wgrad_multi()."""
+    _chk(small, "small")
+    _chk(large, "large")
+    _chk(out, "out")
+    nb0, Ts, A = small.shape
+    Tl, Bc = large.shape[1], large.shape[2]
+    pad = (K - 1) // 2
+    if large.shape[0] != nb0 or ((Tl + 2 * pad - K) // stride + 1 != Ts and not (stride == 2 and Tl == 2 * Ts)):
+        raise ValueError(f"wgrad: S {tuple(small.shape)} inconsistent with L {tuple(large.shape)}, K={K}, stride={stride}")
+    if out.numel() != A * Bc * K:
+        raise ValueError(f"wgrad: out numel {out.numel()} != {A * Bc * K}")
+    nb1 = 0
+    if small2 is not None:
+        _chk(small2, "small2")
+        _chk(large2, "large2")
+        nb1 = small2.shape[0]
+        if tuple(small2.shape[1:]) != (Ts, A) or tuple(large2.shape) != (nb1, Tl, Bc):
+            raise ValueError("wgrad: segment 1 shape mismatch")
+    if bias_out is not None:
+        if bias_from not in (1, 2):
+            raise ValueError("wgrad: bias_from must be 1 (S) or 2 (L) when bias_out is given")
+        _chk(bias_out, "bias_out", (A if bias_from == 1 else Bc,))
+    elif bias_from:
+        raise ValueError("wgrad: bias_from without bias_out")
+    return (small, large, nb0, small2, large2, nb1, out, bias_out, bias_from, Ts, Tl, A, Bc, K, stride)
+
+
+def wgrad_multi(jobs):
+    """Independent weight gradients of one (K, stride), given as _wgrad_job tuples (conv1d_wgrad / convT1d_wgrad /
+    linear_wgrad with defer=True return them), in ONE launch (+ one reduce launch if any of them is split over the
+    batch): the small layers' gradients are each a few workgroups at the launch floor.  More than MG_MAX_WGRAD_JOBS
+    jobs, or jobs of different (K, stride), go out as several launches."""
+    lib = L.load()
+    groups = {}
+    for j in jobs:
+        groups.setdefault((j[13], j[14]), []).append(j)
+    for (K, stride), js in groups.items():
+        for i in range(0, len(js), L.MAX_WGRAD_JOBS):
+            part = js[i:i + L.MAX_WGRAD_JOBS]
+            arr = (L.WgradJob * len(part))()
+            need, flops = 0, 0.0
+            for a, (s0, l0, nb0, s1, l1, nb1, out, bo, bf, Ts, Tl, A, Bc, _, _) in zip(arr, part):
+                a.s0, a.l0, a.nb0 = s0.data_ptr(), l0.data_ptr(), nb0
+                a.s1, a.l1, a.nb1 = (None if s1 is None else s1.data_ptr()), (None if l1 is None else l1.data_ptr()), nb1
+                a.out, a.bias_out, a.bias_from = out.data_ptr(), (None if bo is None else bo.data_ptr()), bf
+                a.Ts, a.Tl, a.A, a.Bc = Ts, Tl, A, Bc
+                need += (lib.mg_wgrad_workspace_bytes(A, Bc, K, nb0 + nb1, Ts) + 255) & ~255
+                flops += 2.0 * (nb0 + nb1) * Ts * A * Bc * K
+            work = workspace(need, part[0][0].device, "wgrad_multi")
+            with _observe(lambda: f"wgrad_multi_kernel<{stride},{K}>", flops):
+                rc = lib.mg_wgrad_multi(arr, len(part), K, stride, _p(work), work.numel() * work.element_size(), _stream())
+            L.check(rc, "mg_wgrad_multi")
+
+
+def conv1d_wgrad(x, dy, dw, stride, x2=None, dy2=None, db=None, defer=False):
+    """dw (Cout, Cin, K) for nn.Conv1d: S = dy, L = x; db (Cout) = column sums of dy (segment 0) if given.
+    defer=True: nothing is launched, the job is returned for wgrad_multi()."""
     K = dw.shape[2]
+    if defer:
+        return _wgrad_job(dy, x, dw, K, stride, dy2, x2, db, 1 if db is not None else 0)
     return wgrad(dy, x, dw, K, stride, dy2, x2, bias_out=db, bias_from=1 if db is not None else 0)
 
 
-def convT1d_wgrad(x, dy, dw, db=None):
+def convT1d_wgrad(x, dy, dw, db=None, defer=False):
     """dw (Cin, Cout, 5) for the stride-2 ConvTranspose1d: S = x, L = dy; db (Cout) = column sums of dy if given."""
+    if defer:
+        return _wgrad_job(x, dy, dw, 5, 2, None, None, db, 2 if db is not None else 0)
     return wgrad(x, dy, dw, 5, 2, bias_out=db, bias_from=2 if db is not None else 0)
 
 
-def linear_wgrad(x, dy, dw, x2=None, dy2=None, db=None):
+def linear_wgrad(x, dy, dw, x2=None, dy2=None, db=None, defer=False):
     """dw (out, in) = dy^T @ x (+ second segment); db (out) = column sums of dy (segment 0) if given."""
     B = x.shape[0]
     s2 = l2 = None
     if x2 is not None:
         s2, l2 = dy2.view(dy2.shape[0], 1, -1), x2.view(x2.shape[0], 1, -1)
+    if defer:
+        return _wgrad_job(dy.view(B, 1, -1), x.view(B, 1, -1), dw, 1, 1, s2, l2, db, 1 if db is not None else 0)
     return wgrad(dy.view(B, 1, -1), x.view(B, 1, -1), dw, 1, 1, s2, l2, bias_out=db, bias_from=1 if db is not None else 0)
 
 

@@ -364,3 +364,38 @@ def test_tick_free_draw_and_update_match_the_plain_pair(ops):
     for x, y in zip(a[5], b[5]):
         assert torch.equal(x, y)
     assert int(b[4].item()) == 3 and float(b[3][0].item()) == 3.0
+
+
+def test_wgrad_multi_equals_separate_launches():
+    """mg_wgrad_multi: several weight gradients per launch are bit-identical to one launch each (same workgroup body,
+    same split plan, same reduction order): Linear layers (unsplit), stride-2 K=5 conv / convT gradients with fused
+    bias sums and batch splits, a two-segment job, ragged channel counts, and more jobs than one launch holds."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).cuda()  # noqa: E731
+    jobs, want = [], []
+
+    def both(fn, *a, outs, **k):
+        fn(*a, **k)
+        want.append([o.clone() for o in outs])
+        for o in outs:
+            o.fill_(float("nan"))
+        jobs.append((fn(*a, defer=True, **k), outs))
+
+    for (B, i, o) in [(64, 64, 512), (64, 512, 64), (64, 256, 512), (64, 6, 256), (64, 256, 128), (64, 128, 128),
+                      (192, 256, 256), (64, 40, 72), (64, 128, 4), (30, 100, 36)]:
+        x, dy, dw, db = r(B, i), r(B, o), torch.empty(o, i).cuda(), torch.empty(o).cuda()
+        both(ops.linear_wgrad, x, dy, dw, db=db, outs=[dw, db])
+    x, dy, x2, dy2, dw = r(16, 24), r(16, 40), r(8, 24), r(8, 40), torch.empty(40, 24).cuda()
+    both(ops.linear_wgrad, x, dy, dw, x2=x2, dy2=dy2, outs=[dw])
+    for (B, T, ci, co) in [(64, 32, 256, 128), (64, 64, 128, 64), (64, 128, 64, 128), (5, 16, 20, 12)]:
+        x, dy, dw, db = r(B, T, ci), r(B, 2 * T, co), torch.empty(ci, co, 5).cuda(), torch.empty(co).cuda()
+        both(ops.convT1d_wgrad, x, dy, dw, db=db, outs=[dw, db])
+    for (B, T, ci, co) in [(192, 64, 128, 256), (24, 32, 64, 128)]:
+        x, dy, dw, db = r(B, T, ci), r(B, T // 2, co), torch.empty(co, ci, 5).cuda(), torch.empty(co).cuda()
+        both(ops.conv1d_wgrad, x, dy, dw, 2, db=db, outs=[dw, db])
+    ops.wgrad_multi([j for j, _ in jobs])
+    for (_, outs), ws in zip(jobs, want):
+        for o, w in zip(outs, ws):
+            assert torch.equal(o, w)
