@@ -158,15 +158,16 @@ class EdEngine:
         ops.softmax_ce(self.logits, self.y, self.loss, self.dlogits, 1.0)
         n = len(self.mlp)
         g, wname, inp = self.dlogits, "classifier.head", self.ca[n - 1]
+        jobs = []        # weight gradients: collected, launched together at the end (ops.wgrad_multi)
         for j in reversed(range(n)):
-            ops.linear_wgrad(inp, g, G[wname + ".weight"], db=G[wname + ".bias"])
+            jobs.append(ops.linear_wgrad(inp, g, G[wname + ".weight"], db=G[wname + ".bias"], defer=True))
             # d/d(pre-activation) = dropout mask * GELU'(cz)
             ops.linear_dgrad(g, P[wname + ".weight"], self.dcz[j], gref=self.cz[j], gact=ACT_GELU, emul=self.dmask[j])
             g, wname = self.dcz[j], f"classifier.net.{3 * j}"
             inp = self.ca[j - 1] if j > 0 else self.proj
-        ops.linear_wgrad(self.proj, g, G[wname + ".weight"], db=G[wname + ".bias"])
+        jobs.append(ops.linear_wgrad(self.proj, g, G[wname + ".weight"], db=G[wname + ".bias"], defer=True))
         ops.linear_dgrad(g, P[wname + ".weight"], self.dproj)
-        ops.linear_wgrad(self.pool, self.dproj, G["encoder.project.weight"], db=G["encoder.project.bias"])
+        jobs.append(ops.linear_wgrad(self.pool, self.dproj, G["encoder.project.weight"], db=G["encoder.project.bias"], defer=True))
         ops.linear_dgrad(self.dproj, P["encoder.project.weight"], self.dpool)
         last = len(self.chans) - 1
         ops.meanT_bwd(self.dpool, self.da[last])
@@ -175,9 +176,10 @@ class EdEngine:
             ops.bn_train_bwd(self.da[i], self.a[i], self.z[i], self.dz[i], P[pre + "1.weight"], self.bn_mean[i],
                              self.bn_invstd[i], G[pre + "1.weight"], G[pre + "1.bias"], act=ACT_GELU, beta=P[pre + "1.bias"])
             xin = self.a[i - 1] if i > 0 else self.x
-            ops.conv1d_wgrad(xin, self.dz[i], G[pre + "0.weight"], 1, db=G[pre + "0.bias"])
+            jobs.append(ops.conv1d_wgrad(xin, self.dz[i], G[pre + "0.weight"], 1, db=G[pre + "0.bias"], defer=True))
             if i > 0:
                 ops.conv1d_dgrad(self.dz[i], P[pre + "0.weight"], self.da[i - 1], 1)
+        ops.wgrad_multi(jobs)
 
     def backward_rng(self):
         self.draw_masks()

@@ -41,6 +41,8 @@ class DataParallel:
             self.mode = "allreduce"
         if self.active and self.mode == "gather":
             engine.enable_p2_gather(self.world)
+        if self.active and self.mode == "overlap":
+            engine.p2_in_a2 = True       # pre.2's weight gradient must exist when g_backward_a2 ends
         engine.world_size = self.world
         self._pending = []
 

@@ -280,6 +280,7 @@ class GanEngine:
         self.branch_mode = os.environ.get("MELO_BRANCH", "none")
         self.world_size = 1
         self.p2_world = 0          # > 0: decoder.pre.2's weight gradient comes from all-gathered factors (enable_p2_gather)
+        self.p2_in_a2 = False      # True: pre.2's weight gradient is launched by g_backward_a2 (DataParallel 'overlap' mode)
         self._ed_folded = False
 
     # -------------------------------------------------------------------------------------
@@ -650,8 +651,9 @@ class GanEngine:
             # data parallel, factor gather: only the bias gradient here (it travels with the small all-reduce); the
             # weight gradient is computed by g_backward_p2b from every rank's (d_p2, a_p0)
             ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
-        else:
+        elif self.p2_in_a2:
             ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"))
+        # otherwise g_backward_b launches it together with the other Linear weight gradients
         self._join()
 
     def g_backward_b(self, extra_jobs=()):
@@ -663,6 +665,9 @@ class GanEngine:
         # Linear layers, 12 launches at the launch floor before.
         dn = self.dn_dense if self.dn_dense is not None else self.dnotes
         jobs = list(extra_jobs)
+        if not self.p2_world and not self.p2_in_a2:
+            jobs.append(ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
+                                         defer=True))
         jobs.append(ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"), defer=True))
         jobs.append(ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"),
                                       defer=True))
