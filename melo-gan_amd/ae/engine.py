@@ -156,13 +156,14 @@ class VaeEngine:
         # tanh' and (if T % 8 != 0) drop the zero-padded tail rows
         ops.act_bwd(self.g_recon, self.g_recon, gref=self.recon, gact=ACT_TANH)
         dn = self.g_recon
+        jobs = []        # weight gradients: collected, launched together at the end (ops.wgrad_multi)
         if self.g_rec_dense is not None:
             ops.copy_cols(self.g_recon.view(B, -1), 0, self.g_rec_dense.view(B, -1), 0, self.Ld[3] * 4)
             dn = self.g_rec_dense
         ins = [self.y0, self.da_[0], self.da_[1]]
         for j in (2, 1, 0):
             i = DEC[j][0]
-            ops.convT1d_wgrad(ins[j], dn, g[f"decoder.deconv.{i}.weight"], db=g[f"decoder.deconv.{i}.bias"])
+            jobs.append(ops.convT1d_wgrad(ins[j], dn, g[f"decoder.deconv.{i}.weight"], db=g[f"decoder.deconv.{i}.bias"], defer=True))
             if j == 0:
                 ops.convT1d_dgrad(dn, p[f"decoder.deconv.{i}.weight"], self.g_y0)
                 break
@@ -173,17 +174,17 @@ class VaeEngine:
             dn = self.g_dz[j - 1]
         ops.transpose_bcl_blc(self.g_y0, self.g_p2.view(B, 128, self.red))
         ops.act_bwd(self.g_p2, self.g_p2, gref=self.p2, gact=ACT_RELU)
-        ops.linear_wgrad(self.p0, self.g_p2, g["decoder.pre.2.weight"], db=g["decoder.pre.2.bias"])
+        jobs.append(ops.linear_wgrad(self.p0, self.g_p2, g["decoder.pre.2.weight"], db=g["decoder.pre.2.bias"], defer=True))
         ops.linear_dgrad(self.g_p2, p["decoder.pre.2.weight"], self.g_p0, gref=self.p0, gact=ACT_RELU)
-        ops.linear_wgrad(self.zl, self.g_p0, g["decoder.pre.0.weight"], db=g["decoder.pre.0.bias"])
+        jobs.append(ops.linear_wgrad(self.zl, self.g_p0, g["decoder.pre.0.weight"], db=g["decoder.pre.0.bias"], defer=True))
         ops.linear_dgrad(self.g_p0, p["decoder.pre.0.weight"], self.g_z)
         ops.reparam_bwd(self.g_z, self.lv, self.eps, self.k_mu, self.k_lv, self.g_mu, self.g_lv)
-        ops.linear_wgrad(self.h, self.g_mu, g["fc_mu.weight"], db=g["fc_mu.bias"])
-        ops.linear_wgrad(self.h, self.g_lv, g["fc_log_var.weight"], db=g["fc_log_var.bias"])
+        jobs.append(ops.linear_wgrad(self.h, self.g_mu, g["fc_mu.weight"], db=g["fc_mu.bias"], defer=True))
+        jobs.append(ops.linear_wgrad(self.h, self.g_lv, g["fc_log_var.weight"], db=g["fc_log_var.bias"], defer=True))
         ops.linear_dgrad(self.g_mu, p["fc_mu.weight"], self.g_h)
         ops.linear_dgrad(self.g_lv, p["fc_log_var.weight"], self.g_h, accumulate=True)
         ops.act_bwd(self.g_h, self.g_h, gref=self.h, gact=ACT_RELU)
-        ops.linear_wgrad(self.flat, self.g_h, g["encoder._linear.1.weight"], db=g["encoder._linear.1.bias"])
+        jobs.append(ops.linear_wgrad(self.flat, self.g_h, g["encoder._linear.1.weight"], db=g["encoder._linear.1.bias"], defer=True))
         ops.linear_dgrad(self.g_h, p["encoder._linear.1.weight"], self.g_flat)
         ops.transpose_bcl_blc(self.g_flat.view(B, 128, self.Lenc), self.g_ea[2])      # back to (B, L, 128)
         ins = [self.x, self.ea[0], self.ea[1]]
@@ -192,9 +193,10 @@ class VaeEngine:
             nm = f"encoder.conv.{i + 1}"
             ops.bn_train_bwd(self.g_ea[j], self.ea[j], self.ez[j], self.g_ez[j], p[nm + ".weight"], self.e_mean[j],
                              self.e_istd[j], g[nm + ".weight"], g[nm + ".bias"], ACT_RELU)
-            ops.conv1d_wgrad(ins[j], self.g_ez[j], g[f"encoder.conv.{i}.weight"], 2, db=g[f"encoder.conv.{i}.bias"])
+            jobs.append(ops.conv1d_wgrad(ins[j], self.g_ez[j], g[f"encoder.conv.{i}.weight"], 2, db=g[f"encoder.conv.{i}.bias"], defer=True))
             if j > 0:
                 ops.conv1d_dgrad(self.g_ez[j], p[f"encoder.conv.{i}.weight"], self.g_ea[j - 1], 2)
+        ops.wgrad_multi(jobs)
 
     def update(self):
         """clip_grad_norm_(1.0) (train_ae.py:121) folded into the fused AdamW through a device scalar."""
