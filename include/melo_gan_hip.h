@@ -220,15 +220,18 @@ int mg_axpby(const float* x, float* y, float a, float b, long n, mg_stream_t str
 /* dst[r, doff + j] = src[r, soff + j] for j < ncols (row-major 2-D copy; accumulate adds) */
 int mg_copy_cols(const float* src, int sld, int soff, float* dst, int dld, int doff,
                  int rows, int ncols, int accumulate, mg_stream_t stream);
-/* (B, C, L) <-> (B, L, C): out[b, l, c] = in[b, c, l]  (src/gan/models.py:70 view + :73 permute) */
-int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, mg_stream_t stream);
+/* (B, C, L) <-> (B, L, C): out[b, l, c] = in[b, c, l]  (src/gan/models.py:70 view + :73 permute); with gref (laid
+ * out like `out`) the result is multiplied by act'(gref): the activation backward of the layer behind the view. */
+int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, const float* gref, int gact,
+                         mg_stream_t stream);
 /* y = x * act'(gref) * emul   (standalone epilogue pieces for tiny tensors) */
 int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, float* dx, long n,
                mg_stream_t stream);
 
 /* ---- batch staging (the device side of the DataLoader collate + .to(device) of src/gan/train_gan.py:80,172-178):
  *      for every job, dst row r <- src row (idx ? idx[r] : r) for r < n_rows, ALL jobs in one launch.  Rows are
- *      row_bytes long (a multiple of 4; 16-byte aligned rows take the 16-byte path), dst rows are dense.  idx is a
+ *      row_bytes long (a multiple of 4; 16-byte aligned rows take the 16-byte path); dst rows are dst_pitch bytes
+ *      apart (0: dense), so a job can also fill a column block of a wider matrix.  idx is a
  *      device array of n_rows int64 indices, clamped into [0, src_rows) on the device (an out-of-range index never
  *      reads outside the source). */
 #define MG_MAX_STAGE_JOBS 8
@@ -238,6 +241,7 @@ typedef struct mg_stage_job {
     const int64_t* idx; /* NULL: straight copy of the first n_rows rows */
     long row_bytes;
     long src_rows;
+    long dst_pitch;     /* bytes between destination rows; 0 = row_bytes */
 } mg_stage_job;
 int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t stream);
 

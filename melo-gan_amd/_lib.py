@@ -17,7 +17,7 @@ class Epilogue(C.Structure):
 
 
 class StageJob(C.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("idx", vp), ("row_bytes", i64), ("src_rows", i64)]
+    _fields_ = [("src", vp), ("dst", vp), ("idx", vp), ("row_bytes", i64), ("src_rows", i64), ("dst_pitch", i64)]
 
 
 MAX_STAGE_JOBS = 8
@@ -66,7 +66,7 @@ SIGNATURES = {
     "mg_fill": (i32, [vp, f32, i64, vp]),
     "mg_axpby": (i32, [vp, vp, f32, f32, i64, vp]),
     "mg_copy_cols": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
-    "mg_transpose_bcl_blc": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mg_transpose_bcl_blc": (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
     "mg_stage_rows": (i32, [vp, i32, i32, vp]),
     "mg_act_bwd": (i32, [vp, vp, i32, vp, vp, i64, vp]),
     "mg_rng_fill": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp]),

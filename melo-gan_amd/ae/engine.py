@@ -172,8 +172,7 @@ class VaeEngine:
             ops.bn_train_bwd(self.g_da[j - 1], self.da_[j - 1], self.dz_[j - 1], self.g_dz[j - 1], p[nm + ".weight"],
                              self.d_mean[j - 1], self.d_istd[j - 1], g[nm + ".weight"], g[nm + ".bias"], ACT_RELU)
             dn = self.g_dz[j - 1]
-        ops.transpose_bcl_blc(self.g_y0, self.g_p2.view(B, 128, self.red))
-        ops.act_bwd(self.g_p2, self.g_p2, gref=self.p2, gact=ACT_RELU)
+        ops.transpose_bcl_blc(self.g_y0, self.g_p2.view(B, 128, self.red), gref=self.p2, gact=ACT_RELU)
         jobs.append(ops.linear_wgrad(self.p0, self.g_p2, g["decoder.pre.2.weight"], db=g["decoder.pre.2.bias"], defer=True))
         ops.linear_dgrad(self.g_p2, p["decoder.pre.2.weight"], self.g_p0, gref=self.p0, gact=ACT_RELU)
         jobs.append(ops.linear_wgrad(self.zl, self.g_p0, g["decoder.pre.0.weight"], db=g["decoder.pre.0.bias"], defer=True))

@@ -549,7 +549,7 @@ __global__ void stage_rows_kernel(const StageJobs J, int n_rows) {
         sr = sr < 0 ? 0 : (sr >= job.src_rows ? job.src_rows - 1 : sr);
     }
     const char* s = static_cast<const char*>(job.src) + sr * job.row_bytes;
-    char* d = static_cast<char*>(job.dst) + (long)r * job.row_bytes;
+    char* d = static_cast<char*>(job.dst) + (long)r * (job.dst_pitch ? job.dst_pitch : job.row_bytes);
     const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
     if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)job.row_bytes) & 15) == 0) {
         const long n = job.row_bytes >> 4;
@@ -559,7 +559,8 @@ __global__ void stage_rows_kernel(const StageJobs J, int n_rows) {
         for (long i = first; i < n; i += stride) reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
     }
 }
-__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int L) {
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int L,
+                                 const float* __restrict__ gref, int gact) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
@@ -571,7 +572,12 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int l = l0 + r, c = c0 + tx;
-        if (l < L && c < C) out[((long)b * L + l) * C + c] = tile[tx][r];
+        if (l < L && c < C) {
+            const long o = ((long)b * L + l) * C + c;
+            float v = tile[tx][r];
+            if (gref) v *= mg_act_grad(gact, gref[o]);
+            out[o] = v;
+        }
     }
 }
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ gref, int gact,
@@ -1001,6 +1007,8 @@ int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t 
                          ((((uintptr_t)j.src | (uintptr_t)j.dst)) & 3) == 0 && (j.idx || j.src_rows >= n_rows),
                      "mg_stage_rows: job %d: rows must be non-empty multiples of 4 bytes, 4-byte aligned, and the source "
                      "must hold n_rows rows when it is not indexed", i);
+        MG_CHECK_ARG(j.dst_pitch == 0 || (j.dst_pitch >= j.row_bytes && (j.dst_pitch & 3) == 0),
+                     "mg_stage_rows: job %d: dst_pitch must be 0 or a multiple of 4 that holds a row", i);
         J.j[i] = j;
         widest = j.row_bytes > widest ? j.row_bytes : widest;
     }
@@ -1011,10 +1019,11 @@ int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t 
     return MG_OK;
 }
 
-int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, mg_stream_t stream) {
+int mg_transpose_bcl_blc(const float* in, float* out, int B, int C, int L, const float* gref, int gact,
+                         mg_stream_t stream) {
     MG_CHECK_ARG(in && out && B > 0 && C > 0 && L > 0, "mg_transpose_bcl_blc: bad args");
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)mg_cdiv(L, 32), (unsigned)mg_cdiv(C, 32), (unsigned)B), dim3(256),
-                       0, ST, in, out, C, L);
+                       0, ST, in, out, C, L, gref, gact);
     MG_CHECK_LAUNCH("transpose");
     return MG_OK;
 }

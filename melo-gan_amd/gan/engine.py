@@ -407,10 +407,12 @@ class GanEngine:
     def _g_fwd(self, out: Tensor, train: bool):
         """Generator.forward (src/gan/models.py:108-130, :66-83) into `out` (B, T, C)."""
         P = self._gp
-        ops.copy_cols(self.noise, 0, self.gin, 0, self.noise_dim)
-        ops.copy_cols(self.emb, 0, self.gin, self.noise_dim, self.E)
+        # gin = [noise | embedding (| latent)]: the column blocks filled by one launch
+        nd, E = self.noise_dim, self.E
+        blocks = [(self.noise, self.gin[:, :nd], None), (self.emb, self.gin[:, nd:nd + E], None)]
         if self.mode == "conditioning":
-            ops.copy_cols(self.latent, 0, self.gin, self.noise_dim + self.E, self.latent_dim)
+            blocks.append((self.latent, self.gin[:, nd + E:nd + E + self.latent_dim], None))
+        ops.stage_rows(blocks, self.B)
         ops.linear_fwd(self.gin, P("noise_to_latent.net.0.weight"), self.a_n0, bias=P("noise_to_latent.net.0.bias"), act=ACT_RELU)
         ops.linear_fwd(self.a_n0, P("noise_to_latent.net.2.weight"), self.lat, bias=P("noise_to_latent.net.2.bias"))
         ops.linear_fwd(self.lat, P("decoder.pre.0.weight"), self.a_p0, bias=P("decoder.pre.0.bias"), act=ACT_RELU)
@@ -645,8 +647,7 @@ class GanEngine:
                          self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
         ops.convT1d_dgrad(self.d_zd0, PG("decoder.deconv.0.weight"), self.d_y0)
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
-        ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
-        ops.act_bwd(self.d_p2, self.d_p2, gref=self.a_p2, gact=ACT_RELU)
+        ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red), gref=self.a_p2, gact=ACT_RELU)
         if self.p2_world:
             # data parallel, factor gather: only the bias gradient here (it travels with the small all-reduce); the
             # weight gradient is computed by g_backward_p2b from every rank's (d_p2, a_p0)

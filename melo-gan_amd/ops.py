@@ -644,9 +644,14 @@ def stage_rows(jobs, n_rows):
         raise ValueError(f"stage_rows: 1..{L.MAX_STAGE_JOBS} jobs")
     arr = (L.StageJob * len(jobs))()
     for a, (src, dst, idx) in zip(arr, jobs):
-        for nm, t in (("src", src), ("dst", dst)):
-            if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous() or t.dim() < 1:
-                raise ValueError(f"stage_rows: {nm} must be a contiguous device tensor")
+        if not isinstance(src, torch.Tensor) or not src.is_cuda or not src.is_contiguous() or src.dim() < 1:
+            raise ValueError("stage_rows: src must be a contiguous device tensor")
+        # dst: dense, or a column block of a wider 2-D matrix (rows contiguous, a row pitch between them)
+        dense = isinstance(dst, torch.Tensor) and dst.is_cuda and dst.dim() >= 1 and dst.is_contiguous()
+        block = (isinstance(dst, torch.Tensor) and dst.is_cuda and dst.dim() == 2 and dst.stride(1) == 1 and
+                 dst.stride(0) >= dst.shape[1])
+        if not (dense or block):
+            raise ValueError("stage_rows: dst must be a contiguous device tensor or a column block of one")
         if src.dtype != dst.dtype or src.shape[1:] != dst.shape[1:] or dst.shape[0] < n_rows:
             raise ValueError(f"stage_rows: row mismatch {tuple(src.shape)} {src.dtype} -> {tuple(dst.shape)} {dst.dtype}")
         if idx is not None:
@@ -656,15 +661,20 @@ def stage_rows(jobs, n_rows):
         row_bytes = src.element_size() * (src[0].numel() if src.dim() > 1 else 1)
         a.src, a.dst, a.idx = src.data_ptr(), dst.data_ptr(), (None if idx is None else idx.data_ptr())
         a.row_bytes, a.src_rows = row_bytes, src.shape[0]
+        a.dst_pitch = 0 if dense else dst.stride(0) * dst.element_size()
     L.check(L.load().mg_stage_rows(arr, len(jobs), n_rows, _stream()), "mg_stage_rows")
 
 
-def transpose_bcl_blc(x, y):
-    """y[b, l, c] = x[b, c, l]."""
+def transpose_bcl_blc(x, y, gref=None, gact=ACT_NONE):
+    """y[b, l, c] = x[b, c, l] (* act'(gref[b, l, c]) if gref is given: the activation backward behind the view)."""
     _chk(x, "x")
     B, Cc, Ln = x.shape
     _chk(y, "y", (B, Ln, Cc))
-    L.check(L.load().mg_transpose_bcl_blc(_p(x), _p(y), B, Cc, Ln, _stream()), "mg_transpose_bcl_blc")
+    if gref is not None:
+        _chk(gref, "gref")
+        if gref.numel() != y.numel():
+            raise ValueError("transpose_bcl_blc: gref size mismatch")
+    L.check(L.load().mg_transpose_bcl_blc(_p(x), _p(y), B, Cc, Ln, _p(gref), gact, _stream()), "mg_transpose_bcl_blc")
     return y
 
 

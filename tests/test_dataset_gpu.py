@@ -47,6 +47,11 @@ def test_stage_rows_gathers_and_copies_in_one_launch():
     bad[0], bad[1] = -5, 10 ** 12
     ops.stage_rows([(notes, out[0], bad)], 16)
     assert torch.equal(out[0][0], notes[0]) and torch.equal(out[0][1], notes[36]) and torch.equal(out[0][2:], notes[idx[2:]])
+    # column blocks of a wider matrix (a row pitch between destination rows): [odd | dense | untouched]
+    wide = torch.full((16, 7 + 5 + 3), -2.0).cuda()
+    ops.stage_rows([(odd, wide[:, :7], idx), (dense, wide[:, 7:12], None)], 16)
+    assert torch.equal(wide[:, :7], odd.index_select(0, idx)) and torch.equal(wide[:, 7:12], dense)
+    assert bool((wide[:, 12:] == -2).all())
     with pytest.raises(ValueError):
         ops.stage_rows([(notes, out[1], idx)], 16)                  # row shapes differ
     with pytest.raises(ValueError):

@@ -399,3 +399,16 @@ def test_wgrad_multi_equals_separate_launches():
     for (_, outs), ws in zip(jobs, want):
         for o, w in zip(outs, ws):
             assert torch.equal(o, w)
+
+
+def test_transpose_with_activation_backward():
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(5, 37, 70, generator=g) * 2 - 1).cuda()
+    ref = (torch.rand(5, 70, 37, generator=g) * 2 - 1).cuda()
+    y = torch.empty(5, 70, 37).cuda()
+    ops.transpose_bcl_blc(x, y)
+    assert torch.equal(y, x.transpose(1, 2).contiguous())
+    ops.transpose_bcl_blc(x, y, gref=ref, gact=ops.ACT_RELU)
+    assert torch.equal(y, x.transpose(1, 2) * (ref > 0).float())
