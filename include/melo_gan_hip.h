@@ -188,6 +188,9 @@ int mg_dhead_fwd(const float* f, const float* emb, const float* w, const float* 
 /* dU[b,j] = ds[b]*w[j]*lrelu'(f[b,j]); demb[be,j] (+)= sum over b%Be==be of ds[b]*w[F+j] (if demb) */
 int mg_dhead_bwd(const float* ds, const float* f, const float* w, float* dU, float* demb,
                  int B, int Be, int F, int E, int nb_emb, mg_stream_t stream);
+/* mg_dhead_fwd and mg_dhead_bwd in one launch: ds is a constant of the step, so the backward does not wait for s. */
+int mg_dhead_fwd_bwd(const float* ds, const float* f, const float* emb, const float* w, const float* bias, float* s,
+                     float* dU, float* demb, int B, int Be, int F, int E, int nb_emb, mg_stream_t stream);
 /* dw[j<F] = sum_{b<nb} ds[b] f[b,j] + sum_{b<ng} gf[b,j];  dw[F+j] = sum_{b<nb} ds[b] emb[b%Be,j];
  * dbias = sum_{b<nb} ds[b] */
 int mg_dhead_wgrad(const float* ds, const float* f, const float* emb, const float* gf,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mg_layernorm_bwd_params": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "mg_dhead_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mg_dhead_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mg_dhead_fwd_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mg_dhead_wgrad": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mg_gp_interp": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "mg_gp_penalty": (i32, [vp, vp, vp, vp, f32, i32, i64, vp]),

@@ -380,6 +380,37 @@ __global__ void dhead_demb_kernel(const float* __restrict__ ds, const float* __r
     demb[i] = s * w[F + j];
 }
 
+// Critic head forward AND its input gradient in one launch: the upstream coefficient ds is a constant of the step
+// (-1/B, +1/B, 1: Wasserstein terms and the penalty's grad_outputs), so the backward does not wait for the forward.
+// Block b < B: s[b] and dU[b, :]; blocks B.. (if demb): 64 elements of the embedding gradient each.
+__global__ void dhead_fwd_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ f,
+                                     const float* __restrict__ emb, const float* __restrict__ w,
+                                     const float* __restrict__ bias, float* s, float* dU, float* demb, int B, int Be,
+                                     int F, int E, int nb_emb) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) {
+        const int i = (b - B) * 64 + lane;
+        if (i < Be * E) {
+            const int be = i / E, j = i - be * E;
+            float t = 0.f;
+            for (int r = be; r < nb_emb; r += Be) t += ds[r];
+            demb[i] = t * w[F + j];
+        }
+        return;
+    }
+    const float d = ds[b];
+    float acc = 0.f;
+    for (int j = lane; j < F; j += 64) {
+        const float fv = f[(long)b * F + j], wv = w[j];
+        acc += fv * wv;
+        dU[(long)b * F + j] = d * wv * (fv > 0.f ? 1.f : 0.2f);
+    }
+    if (emb)
+        for (int j = lane; j < E; j += 64) acc += emb[(long)(b % Be) * E + j] * w[F + j];
+    acc = wave_sum(acc);
+    if (lane == 0) s[b] = acc + bias[0];
+}
+
 // one wave per output element j: lanes stride over the batch rows, shuffle-reduce
 __global__ void dhead_wgrad_kernel(const float* __restrict__ ds, const float* __restrict__ f,
                                    const float* __restrict__ emb, const float* __restrict__ gf, float* dw,
@@ -911,6 +942,16 @@ int mg_dhead_bwd(const float* ds, const float* f, const float* w, float* dU, flo
     if (demb)
         hipLaunchKernelGGL(dhead_demb_kernel, dim3(nblk((long)Be * E)), dim3(256), 0, ST, ds, w, demb, Be, F, E, nb_emb);
     MG_CHECK_LAUNCH("dhead_bwd");
+    return MG_OK;
+}
+
+int mg_dhead_fwd_bwd(const float* ds, const float* f, const float* emb, const float* w, const float* bias, float* s,
+                     float* dU, float* demb, int B, int Be, int F, int E, int nb_emb, mg_stream_t stream) {
+    MG_CHECK_ARG(ds && f && w && bias && s && dU && B > 0 && F > 0, "mg_dhead_fwd_bwd: bad args");
+    MG_CHECK_ARG((!emb && !demb) || (Be > 0 && E > 0), "mg_dhead_fwd_bwd: bad emb shape");
+    hipLaunchKernelGGL(dhead_fwd_bwd_kernel, dim3(B + (demb ? (unsigned)mg_cdiv((long)Be * E, 64) : 0)), dim3(64), 0, ST, ds, f, emb, w, bias, s, dU, demb, B,
+                       Be > 0 ? Be : 1, F, (emb || demb) ? E : 0, nb_emb);
+    MG_CHECK_LAUNCH("dhead_fwd_bwd");
     return MG_OK;
 }
 

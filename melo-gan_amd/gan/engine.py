@@ -435,20 +435,27 @@ class GanEngine:
             ops.bn_eval_fwd(z, a, P(name + ".weight"), P(name + ".bias"), self.Gbuf[name + ".running_mean"],
                             self.Gbuf[name + ".running_var"], ACT_RELU, BN_EPS)
 
-    def _d_fwd(self, x: Tensor, nb: int):
-        """Discriminator.forward (src/gan/models.py:158-169) on the first nb rows of the critic buffers."""
+    def _d_fwd(self, x: Tensor, nb: int, head: bool = True):
+        """Discriminator.forward (src/gan/models.py:158-169) on the first nb rows of the critic buffers.  head=False
+        leaves the scoring head to _d_bwd_input(with_head=True), which runs it in the same launch as its gradient."""
         P = self.D.p
         ops.conv1d_fwd(x, P["conv.0.weight"], self.A1[:nb], 2, bias=P["conv.0.bias"], act=ACT_LRELU)
         ops.conv1d_fwd(self.A1[:nb], P["conv.2.weight"], self.A2[:nb], 2, bias=P["conv.2.bias"], act=ACT_LRELU)
         ops.conv1d_fwd(self.A2[:nb], P["conv.4.weight"], self.A3[:nb], 2, bias=P["conv.4.bias"], act=ACT_LRELU)
         ops.meanT_fwd(self.A3[:nb], self.H[:nb])
         ops.linear_fwd(self.H[:nb], P["fc.1.weight"], self.Fh[:nb], bias=P["fc.1.bias"], act=ACT_LRELU)
-        ops.dhead_fwd(self.Fh[:nb], self.emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb])
+        if head:
+            ops.dhead_fwd(self.Fh[:nb], self.emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb])
 
-    def _d_bwd_input(self, ds: Tensor, nb: int, demb: Optional[Tensor]):
+    def _d_bwd_input(self, ds: Tensor, nb: int, demb: Optional[Tensor], with_head: bool = False):
         """Back-propagate ds through the critic down to dZ1 (grad wrt conv.0's pre-activation)."""
         P = self.D.p
-        ops.dhead_bwd(ds, self.Fh[:nb], P["real_fake.weight"].view(-1), self.dU[:nb], demb, nb_emb=nb if demb is not None else 0)
+        if with_head:
+            ops.dhead_fwd_bwd(ds, self.Fh[:nb], self.emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb],
+                              self.dU[:nb], demb, nb_emb=nb if demb is not None else 0)
+        else:
+            ops.dhead_bwd(ds, self.Fh[:nb], P["real_fake.weight"].view(-1), self.dU[:nb], demb,
+                          nb_emb=nb if demb is not None else 0)
         ops.linear_dgrad(self.dU[:nb], P["fc.1.weight"], self.dH[:nb])
         ops.meanT_bwd(self.dH[:nb], self.dZ3[:nb], gref=self.A3[:nb], gact=ACT_LRELU)
         ops.conv1d_dgrad(self.dZ3[:nb], P["conv.4.weight"], self.dZ2[:nb], 2, gref=self.A2[:nb], gact=ACT_LRELU)
@@ -535,9 +542,9 @@ class GanEngine:
         self._e_fwd(train=True)
         self._g_fwd(self.X0[B:2 * B], train=True)
         ops.gp_interp(self.X0[:B], self.X0[B:2 * B], self.alpha, self.X0[2 * B:])
-        self._d_fwd(self.X0, 3 * B)
+        self._d_fwd(self.X0, 3 * B, head=False)
         # one backward for [real | fake | x_hat] with ds = [-1/B | +1/B | 1]
-        self._d_bwd_input(self.ds_d, 3 * B, None)
+        self._d_bwd_input(self.ds_d, 3 * B, None, with_head=True)
         ops.conv1d_dgrad(self.dZ1[2 * B:], P["conv.0.weight"], self.gx, 2)
         ops.gp_penalty(self.gx, self.TAN0, self.norms, None, self.lambda_gp)      # mean((norm-1)^2): in wgan_d_loss
         # Weight gradients are [real,fake] activations x Wasserstein dZ + tangent activations x penalty dZ; each
@@ -619,9 +626,9 @@ class GanEngine:
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         # the critic branch (forward + input gradient) runs beside the emotion-discriminator branch
         with self._branch(0, critic=True):
-            self._d_fwd(self.notes, B)
+            self._d_fwd(self.notes, B, head=False)
+            self._d_bwd_input(self.ds_g, B, self.demb, with_head=True)
             ops.neg_mean(self.s[:B], self.adv)
-            self._d_bwd_input(self.ds_g, B, self.demb)
         self._ed_fwd(self.notes)
         ops.softmax_ce(self.logits, self.emot_idx, self.emo, self.dlogits, self.lambda_emo)
         if self.ed_mode == "notes":

@@ -526,6 +526,25 @@ def dhead_fwd(f, emb, w, bias, s):
     return s
 
 
+def dhead_fwd_bwd(ds, f, emb, w, bias, s, dU, demb=None, nb_emb=0):
+    """dhead_fwd + dhead_bwd in one launch (ds is a constant of the step)."""
+    _chk(f, "f")
+    B, F = f.shape
+    _chk(emb, "emb")
+    Be, E = emb.shape
+    if B % Be or w.numel() != F + E:
+        raise ValueError("dhead_fwd_bwd: shape mismatch")
+    _chk(ds, "ds", (B,))
+    _chk(w, "w")
+    _chk(bias, "bias")
+    _chk(s, "s", (B,))
+    _chk(dU, "dU", (B, F))
+    if demb is not None:
+        _chk(demb, "demb", (Be, E))
+    L.check(L.load().mg_dhead_fwd_bwd(_p(ds), _p(f), _p(emb), _p(w), _p(bias), _p(s), _p(dU), _p(demb), B, Be, F, E, nb_emb,
+                                      _stream()), "mg_dhead_fwd_bwd")
+
+
 def dhead_bwd(ds, f, w, dU, demb=None, nb_emb=0):
     _chk(f, "f")
     B, F = f.shape

@@ -412,3 +412,21 @@ def test_transpose_with_activation_backward():
     assert torch.equal(y, x.transpose(1, 2).contiguous())
     ops.transpose_bcl_blc(x, y, gref=ref, gact=ops.ACT_RELU)
     assert torch.equal(y, x.transpose(1, 2) * (ref > 0).float())
+
+
+def test_dhead_fwd_bwd_equals_separate_launches():
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).cuda()  # noqa: E731
+    for B, Be, with_demb in ((192, 64, False), (64, 64, True), (6, 3, True)):
+        F, E = 256, 128
+        f, emb, w, bias, ds = r(B, F), r(Be, E), r(F + E), r(1), r(B)
+        s0, dU0, de0 = torch.empty(B).cuda(), torch.empty(B, F).cuda(), (torch.empty(Be, E).cuda() if with_demb else None)
+        s1, dU1, de1 = torch.empty(B).cuda(), torch.empty(B, F).cuda(), (torch.empty(Be, E).cuda() if with_demb else None)
+        ops.dhead_fwd(f, emb, w, bias, s0)
+        ops.dhead_bwd(ds, f, w, dU0, de0, nb_emb=B if with_demb else 0)
+        ops.dhead_fwd_bwd(ds, f, emb, w, bias, s1, dU1, de1, nb_emb=B if with_demb else 0)
+        assert torch.equal(s0, s1) and torch.equal(dU0, dU1)
+        if with_demb:
+            assert torch.equal(de0, de1)
