@@ -336,17 +336,26 @@ __global__ void layernorm_fwd_kernel(const float* __restrict__ x, float* __restr
     }
 }
 
-__global__ void layernorm_bwd_params_kernel(const float* dy, const float* xhat, float* dgamma, float* dbeta, int B,
-                                            int D) {
-    const int j = threadIdx.x;
-    if (j >= D) return;
+// 256 threads: feature j = tid % 64, row group tid / 64 takes rows rg, rg+4, ... (four partial sums per feature, added in
+// a fixed order).  One thread per feature walking all B rows was a chain of B dependent loads: 8 us for 64 rows.
+__global__ void layernorm_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, float* dgamma,
+                                            float* dbeta, int B, int D) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int j = threadIdx.x & 63, rg = threadIdx.x >> 6;
     float g = 0.f, bsum = 0.f;
-    for (int b = 0; b < B; ++b) {
-        g += dy[(long)b * D + j] * xhat[(long)b * D + j];
-        bsum += dy[(long)b * D + j];
+    if (j < D)
+        for (int b = rg; b < B; b += 4) {
+            const float d = dy[(long)b * D + j];
+            g += d * xhat[(long)b * D + j];
+            bsum += d;
+        }
+    sg[rg][j] = g;
+    sb[rg][j] = bsum;
+    __syncthreads();
+    if (rg == 0 && j < D) {
+        dgamma[j] = (sg[0][j] + sg[1][j]) + (sg[2][j] + sg[3][j]);
+        dbeta[j] = (sb[0][j] + sb[1][j]) + (sb[2][j] + sb[3][j]);
     }
-    dgamma[j] = g;
-    dbeta[j] = bsum;
 }
 
 // ---------------- critic head ----------------
@@ -921,7 +930,7 @@ int mg_layernorm_fwd(const float* x, float* y, float* xhat, int B, int D, const 
 int mg_layernorm_bwd_params(const float* dy, const float* xhat, float* dgamma, float* dbeta, int B, int D,
                             mg_stream_t stream) {
     MG_CHECK_ARG(dy && xhat && dgamma && dbeta && D <= 64, "mg_layernorm_bwd_params: bad args");
-    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(1), dim3(64), 0, ST, dy, xhat, dgamma, dbeta, B, D);
+    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(1), dim3(256), 0, ST, dy, xhat, dgamma, dbeta, B, D);
     MG_CHECK_LAUNCH("layernorm_bwd_params");
     return MG_OK;
 }
