@@ -75,3 +75,24 @@ def test_two_rank_trainer_gather_equals_allreduce(tmp_path):
                        capture_output=True, text=True, timeout=560)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "largest relative difference gather vs allreduce" in r.stdout
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["gather", "allreduce", "overlap"])
+def test_step_orders_run_on_a_one_rank_rccl_group(mode):
+    """bench.py with MELO_FORCE_DP=1: a 1-rank RCCL ("nccl") process group and the N > 1 step order on this GPU, through
+    warm-up, graph capture and replay.  Guards the interplay of on-stream collectives, the process group's watchdog
+    thread and hipGraph capture (an abort in the first version of this path, ops._quiesce_process_group)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, MELO_FORCE_DP="1", MELO_DP_MODE=mode, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "4", "--no-cpu-baseline",
+                        "--profile-steps", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    for v in line["losses"].values():
+        assert v == v and abs(v) < 1e6
