@@ -26,13 +26,14 @@ testable without GPUs.
 """
 from __future__ import annotations
 
+import os
+
 class DataParallel:
     def __init__(self, engine, world_size: int, dist=None, group=None, force_collectives: bool = False):
         """force_collectives: issue the collectives (and take the overlapped step order) even at world_size 1 -- a
         rehearsal of the N > 1 control path on a single-GPU box."""
         self.engine, self.world, self.dist, self.group = engine, int(world_size), dist, group
         self.active = dist is not None and (self.world > 1 or force_collectives)
-        import os
         self._dry = os.environ.get("MELO_DP_DRY") == "1"      # rehearsal: the N > 1 step order without the collectives
         self.mode = os.environ.get("MELO_DP_MODE", "gather")
         if self.mode not in ("gather", "allreduce", "overlap"):
@@ -125,13 +126,12 @@ class DataParallel:
         docstring).  "gather" / "allreduce": synchronous collectives on the engine's stream; "overlap": asynchronous
         ones on RCCL's stream beside the engine's."""
         e = self.engine
-        e.run("d_backward_rng", use_graph)          # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
         if not self.active:
-            e.run("d_update", use_graph)
+            e.run("d_step_rng", use_graph)                  # draw + D forward/backward + Adam: one graph
             if g_step:
-                e.run("g_backward_rng", use_graph)
-                e.run("g_update", use_graph)
+                e.run("g_step_rng", use_graph)
             return
+        e.run("d_backward_rng", use_graph)          # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
         if not g_step:
             self.allreduce_d()
             e.run("d_update", use_graph)

@@ -578,6 +578,16 @@ class GanEngine:
         self.draw_randoms(with_alpha=False)
         self.g_backward()
 
+    # whole sub-steps as ONE graph each (single-GPU production path: a graph boundary costs ~7 us more than a kernel
+    # boundary inside a graph); the split forms above exist for data parallelism (collectives between them) and tests
+    def d_step_rng(self):
+        self.d_backward_rng()
+        self.d_update()
+
+    def g_step_rng(self):
+        self.g_backward_rng()
+        self.g_update()
+
     def g_backward_a_rng(self):
         self.draw_randoms(with_alpha=False)
         self.g_backward_a()
@@ -736,7 +746,9 @@ class GanEngine:
         try:
             return self._run_graph(key, fn)
         finally:
-            if name.endswith("_rng"):
+            if name.endswith("_step_rng"):                      # draw and update both inside: nothing left pending
+                (self.D if name.startswith("d_") else self.GE).ticked = False
+            elif name.endswith("_rng"):
                 (self.D if name.startswith("d_") else self.GE).ticked = True
             if fp_upd is not None:
                 fp_upd.ticked = False
@@ -763,7 +775,7 @@ class GanEngine:
             st = g
         st.launch()
         if name in ("d_backward", "g_backward", "d_backward_rng", "g_backward_rng", "g_backward_a", "g_backward_a_rng",
-                    "g_forward", "g_forward_rng"):
+                    "g_forward", "g_forward_rng", "d_step_rng", "g_step_rng"):
             self.num_batches_tracked += 1
 
     # -------------------------------------------------------------------------------------
