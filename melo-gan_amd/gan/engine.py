@@ -747,7 +747,7 @@ class GanEngine:
             return self._run_graph(key, fn)
         finally:
             if name.endswith("_step_rng"):                      # draw and update both inside: nothing left pending
-                (self.D if name.startswith("d_") else self.GE).ticked = False
+                self.D.ticked = self.GE.ticked = False
             elif name.endswith("_rng"):
                 (self.D if name.startswith("d_") else self.GE).ticked = True
             if fp_upd is not None:
