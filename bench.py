@@ -158,13 +158,11 @@ def side_workload(args):
         with torch.cuda.stream(eng.stream):
             eng.set_batch(x, y)
             for _ in range(max(args.warmup, 3)):
-                eng.run("backward_rng")
-                eng.run("update")
+                eng.run("step_rng")
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                eng.run("backward_rng")
-                eng.run("update")
+                eng.run("step_rng")
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
         # conv FLOPs: forward + data-gradient (not into the input) + weight-gradient of ED conv0-3

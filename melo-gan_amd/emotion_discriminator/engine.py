@@ -185,6 +185,11 @@ class EdEngine:
         self.draw_masks()
         self.backward()
 
+    def step_rng(self):
+        """Mask draw + forward/backward + AdamW as ONE capturable sequence (one graph launch per training step)."""
+        self.backward_rng()
+        self.update()
+
     def update(self):
         fp = self.P
         ops.adam_flat(fp.data, fp.grad, fp.m, fp.v, fp.state, self.lr, *self.betas,
@@ -219,7 +224,7 @@ class EdEngine:
         finally:
             if name.endswith("_rng"):
                 self.P.ticked = True
-            if name == "update":
+            if name in ("update", "step_rng"):
                 self.P.ticked = False
 
     def forward_eval(self):

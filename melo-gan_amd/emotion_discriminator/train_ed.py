@@ -77,8 +77,7 @@ def run_epoch(eng: EdEngine, x, y, train: bool, use_graph: bool, gen=None):
         idx = perm[i * B:(i + 1) * B]
         eng.set_batch(x.index_select(0, idx), y.index_select(0, idx))
         if train:
-            eng.run("backward_rng", use_graph)
-            eng.run("update", use_graph)
+            eng.run("step_rng", use_graph)
         else:
             eng.run("forward_eval", use_graph)
             ops.softmax_ce(eng.logits, eng.y, eng.loss, None, 1.0)
