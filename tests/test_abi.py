@@ -37,6 +37,22 @@ def test_bad_arguments_are_rejected_on_the_host():
     rc = lib.mg_wgrad(None, None, 0, None, None, 0, None, None, 0, 1, 1, 1, 1, 1, 1, None, 0, None)
     assert rc == -1
     assert lib.mg_wgrad_workspace_bytes(64, 64, 5, 8, 32) > 0
+    # the multi-job entry points: job count limits, null tensors, malformed rows
+    assert lib.mg_wgrad_multi(None, 1, 1, 1, None, 0, None) == -1
+    jobs = (_lib.WgradJob * 1)()
+    assert lib.mg_wgrad_multi(jobs, 0, 1, 1, None, 0, None) == -1
+    assert lib.mg_wgrad_multi(jobs, _lib.MAX_WGRAD_JOBS + 1, 1, 1, None, 0, None) == -1
+    assert lib.mg_wgrad_multi(jobs, 1, 1, 1, None, 0, None) == -1 and b"segment 0" in lib.mg_last_error()
+    st = (_lib.StageJob * 1)()
+    assert lib.mg_stage_rows(st, 0, 4, None) == -1 and lib.mg_stage_rows(st, _lib.MAX_STAGE_JOBS + 1, 4, None) == -1
+    assert lib.mg_stage_rows(st, 1, 4, None) == -1                      # null source / destination
+    st[0].src, st[0].dst, st[0].row_bytes, st[0].src_rows = 256, 512, 6, 8
+    assert lib.mg_stage_rows(st, 1, 4, None) == -1                      # rows must be multiples of 4 bytes
+    st[0].row_bytes, st[0].dst_pitch = 8, 4
+    assert lib.mg_stage_rows(st, 1, 4, None) == -1 and b"dst_pitch" in lib.mg_last_error()
+    st[0].dst_pitch, st[0].src_rows = 0, 2
+    assert lib.mg_stage_rows(st, 1, 4, None) == -1                      # unindexed source shorter than the batch
+    assert lib.mg_dhead_fwd_bwd(None, None, None, None, None, None, None, None, 4, 4, 8, 8, 0, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():
