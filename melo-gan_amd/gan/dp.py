@@ -174,9 +174,10 @@ class DataParallel:
                 self.dist.all_gather_into_tensor(dst, src, group=self.group)
 
     def allreduce_g_rest(self):
-        """Everything of the generator / numeric-encoder gradient except pre.2's weight (first in the flat buffer)."""
-        off, n = self.engine.big_grad_slice()
-        g = self.engine.GE.grad
+        """Everything of the generator / numeric-encoder gradient except pre.2's weight and bias (first in the flat
+        buffer; both come out of the gathered factors as global-batch sums already)."""
+        e = self.engine
+        off, n = e.p2_grad_slice() if hasattr(e, "p2_grad_slice") else e.big_grad_slice()
         if off != 0:
-            raise RuntimeError("gather mode expects decoder.pre.2.weight at offset 0 of the flat gradient")
-        self._allreduce(g[n:])
+            raise RuntimeError("gather mode expects decoder.pre.2 at offset 0 of the flat gradient")
+        self._allreduce(e.GE.grad[n:])

@@ -115,8 +115,8 @@ def emotion_disc_spec(cfg: dict):
 class FlatParams:
     """All tensors of one optimiser in a single flat fp32 buffer (+ grads, Adam m/v, step state)."""
 
-    def __init__(self, spec: "OrderedDict[str, tuple]", device, with_opt: bool = True, first: Optional[str] = None):
-        """`first`: tensor placed at offset 0 of the flat buffers (the dict order stays the spec's) -- the data-parallel
+    def __init__(self, spec: "OrderedDict[str, tuple]", device, with_opt: bool = True, first=None):
+        """`first`: tensor (or list of tensors) placed at offset 0 of the flat buffers (the dict order stays the spec's) -- the data-parallel
         wrapper all-reduces that tensor's gradient early and everything behind it as ONE contiguous range."""
         self.spec = spec
         self.n = sum(math.prod(s) for s in spec.values())
@@ -125,7 +125,8 @@ class FlatParams:
         self.p: Dict[str, Tensor] = OrderedDict()
         self.offsets = {}
         off = 0
-        for k in ([first] if first else []) + [k for k in spec if k != first]:
+        first = [first] if isinstance(first, str) else list(first or [])
+        for k in first + [k for k in spec if k not in first]:
             n = math.prod(spec[k])
             self.offsets[k] = (off, n)
             off += n
@@ -185,7 +186,7 @@ class GanEngine:
         gspec = generator_spec(self.noise_dim, self.latent_dim, self.mode, 512, T, C, self.E)
         espec = feature_encoder_spec(self.num_in, self.enc_hidden, self.E)
         ge = OrderedDict([("G." + k, s) for k, s in gspec.items()] + [("E." + k, s) for k, s in espec.items()])
-        self.GE = FlatParams(ge, d, first="G.decoder.pre.2.weight")
+        self.GE = FlatParams(ge, d, first=["G.decoder.pre.2.weight", "G.decoder.pre.2.bias"])
         self.D = FlatParams(discriminator_spec(C, 256, self.E), d)
         edspec, edbufs, self.ed_chans = emotion_disc_spec(self.ed_cfg)
         self.ED = FlatParams(edspec, d, with_opt=False)
@@ -596,6 +597,13 @@ class GanEngine:
         """(offset, numel) of decoder.pre.2.weight's gradient inside the flat G+E_num gradient buffer."""
         return self.GE.offsets["G.decoder.pre.2.weight"]
 
+    def p2_grad_slice(self):
+        """(offset, numel) of decoder.pre.2's weight AND bias gradients (adjacent, at the front of the flat buffer):
+        what the factor-gather mode computes for the global batch and therefore keeps out of the all-reduce."""
+        (ow, nw), (ob, nb) = self.GE.offsets["G.decoder.pre.2.weight"], self.GE.offsets["G.decoder.pre.2.bias"]
+        assert ow == 0 and ob == nw
+        return 0, nw + nb
+
     def _adam(self, fp, lr):
         """The optimiser step; after draw_randoms() the Adam state is already advanced (fp.ticked)."""
         ops.adam_flat(fp.data, fp.grad, fp.m, fp.v, fp.state, lr, *self.betas, grad_scale=1.0 / self.world_size,
@@ -666,9 +674,7 @@ class GanEngine:
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red), gref=self.a_p2, gact=ACT_RELU)
         if self.p2_world:
-            # data parallel, factor gather: only the bias gradient here (it travels with the small all-reduce); the
-            # weight gradient is computed by g_backward_p2b from every rank's (d_p2, a_p0)
-            ops.colsum(self.d_p2, GG("decoder.pre.2.bias"))
+            pass    # data parallel, factor gather: g_backward_p2b computes weight and bias gradient from every rank's (d_p2, a_p0)
         elif self.p2_in_a2:
             ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"))
         # otherwise g_backward_b launches it together with the other Linear weight gradients
@@ -725,7 +731,8 @@ class GanEngine:
     def g_backward_p2b(self):
         """Second half of the G-step backward under enable_p2_gather: pre.2's global weight gradient from the gathered
         factors, then everything g_backward_b does."""
-        self.g_backward_b([ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"], defer=True)])
+        self.g_backward_b([ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"],
+                                            db=self.GE.g["G.decoder.pre.2.bias"], defer=True)])
 
     def g_update(self):
         self._adam(self.GE, self.lr_g)

@@ -40,8 +40,8 @@ def test_factor_gather_equals_summed_shard_gradients():
         e.g_backward()
         ref.append(e.GE.grad.clone())
     want = ref[0] + ref[1]
-    off, n = engs[0].big_grad_slice()
-    assert off == 0 and n == 256 * engs[0].red * 512
+    off, n = engs[0].p2_grad_slice()                    # pre.2's weight and bias: adjacent, first in the flat buffer
+    assert off == 0 and n == 256 * engs[0].red * 512 + 256 * engs[0].red
 
     # gather mode
     for e, x in zip(engs, inputs):
@@ -61,7 +61,7 @@ def test_factor_gather_equals_summed_shard_gradients():
     rest = engs[0].GE.grad[n:] + engs[1].GE.grad[n:]                         # the remaining all-reduce
     assert rel_err(rest, want[n:]) < 2e-6
     o, m = engs[0].GE.offsets["G.decoder.pre.2.bias"]
-    assert o >= n and rel_err(rest[o - n:o - n + m], want[o:o + m]) < 2e-6   # bias: local column sums, then all-reduced
+    assert o + m == n and rel_err(engs[0].GE.grad[o:o + m], want[o:o + m]) < 2e-6   # bias: column sums of the gathered d_p2
 
 
 @pytest.mark.timeout(600)
