@@ -44,7 +44,10 @@ def vae_spec(max_notes: int, latent_dim: int, hidden_dim: int = 512):
 
 
 class VaeEngine:
-    def __init__(self, cfg: dict, device="cuda", batch_size: Optional[int] = None):
+    def __init__(self, cfg: dict, device="cuda", batch_size: Optional[int] = None, share: Optional["VaeEngine"] = None):
+        """share: another VaeEngine whose parameters, optimiser state and BatchNorm buffers this one uses as its own --
+        the same model at a different batch size (the validation loader's trailing partial batch, train_ae.py:67, and
+        the batch-1 reconstructions of train_ae.py:173-188)."""
         self.cfg = dict(cfg)
         self.dev = torch.device(device)
         B = self.B = int(batch_size or cfg.get("BATCH_SIZE", 32))
@@ -55,8 +58,14 @@ class VaeEngine:
         self.lr, self.wd = float(cfg.get("LR", 1e-4)), float(cfg.get("WEIGHT_DECAY", 1e-5))
         spec, bufs, self.Lenc, self.red = vae_spec(T, self.latent)
         d = self.dev
-        self.P = FlatParams(spec, d)
-        self.buf = {k: (torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d)) for k, s in bufs.items()}
+        if share is not None:
+            if share.P.spec != spec:
+                raise ValueError("VaeEngine(share=...): the two engines must have the same model configuration")
+            self.P, self.buf = share.P, share.buf
+        else:
+            self.P = FlatParams(spec, d)
+            self.buf = {k: (torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d)) for k, s in bufs.items()}
+        self._tails = {}
         z = lambda *s: torch.zeros(*s, device=d)  # noqa: E731
         self.x, self.eps = z(B, T, 4), z(B, self.latent)
         Ts = [T]
@@ -91,8 +100,18 @@ class VaeEngine:
         self.g_ea = [torch.zeros_like(t) for t in self.ea]
         self.g_ez = [torch.zeros_like(t) for t in self.ez]
         self.num_batches_tracked = 0
-        self.stream = torch.cuda.Stream(device=d)
+        self.stream = share.stream if share is not None else torch.cuda.Stream(device=d)
         self.world_size = 1
+
+    def tail(self, rows: int) -> "VaeEngine":
+        """The same model (shared parameters and buffers) at a batch of `rows` samples."""
+        if rows == self.B:
+            return self
+        if rows <= 0:
+            raise ValueError("tail: rows must be positive")
+        if rows not in self._tails:
+            self._tails[rows] = VaeEngine(self.cfg, self.dev, rows, share=self)
+        return self._tails[rows]
 
     def load_state(self, P, Bf):
         self.P.load(P)

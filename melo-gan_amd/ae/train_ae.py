@@ -9,7 +9,9 @@ Per batch (train_ae.py:110-122): forward, MSE + beta*KLD, backward, clip_grad_no
 VaeEngine.  Per epoch (train_ae.py:101-107,126-199): KL warm-up beta, validation with beta=1, ReduceLROnPlateau
 (factor 0.5, patience 5, min_lr 1e-6), best-checkpoint, early stopping.  Data: row-aligned
 <SPLITS_DIR>/{train,val}/notes.npy arrays kept in HBM (the reference's per-file .npz loader with in-loader
-augmentation -- all augmentations are disabled by its config -- is host I/O and out of scope).
+augmentation -- all augmentations are disabled by its config -- is host I/O and out of scope).  Per epoch the first
+(up to) 6 validation rolls are reconstructed in eval mode and written as <RECON_DIR>/ep<E>_val<NNN>_{in,out}.mid
+(train_ae.py:94,173-188; RECON_FREQ, RECON_DIR) through melo_gan_amd.midi.
 """
 import argparse
 import os
@@ -17,6 +19,8 @@ import os
 import numpy as np
 import torch
 
+from .. import ops
+from ..midi import save_recon_midi
 from ..gan.config import load_config
 from ..gan.train_gan import _scalar_writer
 from .engine import VaeEngine
@@ -73,15 +77,18 @@ def train(cfg, synthetic: int = 0):
             tr = (acc / max(1, nb)).tolist()
             acc.zero_()
             vb = 0
-            for i in range(0, len(val_x) - B + 1, B):             # validation: eval-mode BN, beta = 1
-                eng.x.copy_(val_x[i:i + B])
-                eng.eps.copy_(eps.normal_())
-                eng.forward(train=False)
-                from .. import ops
-                ops.vae_loss(eng.recon, eng.x, eng.mu, eng.lv, 1.0, eng.loss)
-                acc += eng.loss
+            # validation: eval-mode BN, beta = 1; drop_last=False (train_ae.py:67), every batch counts once (:153-155)
+            for i in range(0, len(val_x), B):
+                e = eng.tail(min(B, len(val_x) - i))
+                e.x.copy_(val_x[i:i + e.B])
+                e.eps.copy_(eps[:e.B].normal_())
+                e.forward(train=False)
+                ops.vae_loss(e.recon, e.x, e.mu, e.lv, 1.0, e.loss)
+                acc += e.loss
                 vb += 1
-            va = (acc / max(1, vb)).tolist()
+            if vb == 0:
+                raise ValueError("the validation split is empty")
+            va = (acc / vb).tolist()
             # ReduceLROnPlateau(factor 0.5, patience 5, min_lr 1e-6), train_ae.py:80
             if va[0] < sched_best * (1 - 1e-4):
                 sched_best, sched_bad = va[0], 0
@@ -95,6 +102,15 @@ def train(cfg, synthetic: int = 0):
                            ("loss/val_total", va[0]), ("loss/val_recon", va[1]), ("loss/val_kld", va[2]),
                            ("lr", eng.lr), ("beta", beta)):
                 writer.add_scalar(tag, v, epoch)
+            # reconstructions of the first (up to) 6 validation rolls, eval mode, batch 1 (train_ae.py:94,173-188)
+            if epoch % cfg.get("RECON_FREQ", 1) == 0:
+                recon_dir = cfg.get("RECON_DIR", os.path.join(log_dir, "reconstructions"))
+                e1 = eng.tail(1)
+                for j in range(min(6, len(val_x))):
+                    e1.x.copy_(val_x[j:j + 1])
+                    e1.eps.copy_(eps[:1].normal_())
+                    e1.forward(train=False)
+                    save_recon_midi(val_x[j].cpu().numpy(), e1.recon[0].cpu().numpy(), recon_dir, f"ep{epoch}_val{j:03d}")
             if va[0] < best_val:
                 best_val, no_improve = va[0], 0
                 torch.save({"epoch": epoch, "model_state": state_dict(eng)}, os.path.join(model_dir, "ae_best.pth"))

@@ -550,11 +550,14 @@ __global__ void softmax_ce_kernel(const float* __restrict__ logits, const int64_
         float se = 0.f;
         for (int j = 0; j < C; ++j) se += expf(z[j] - mx);
         const float lse = mx + logf(se);
-        const int y = (int)target[b];
-        l += lse - z[y];
+        const int64_t y = target[b];
+        // a target outside [0, C) is an error in the reference (CrossEntropyLoss raises); the host validates labels when
+        // a dataset is built (gan/utils.py::check_labels) -- here such a row poisons the loss instead of reading z[y]
+        const bool bad = y < 0 || y >= C;
+        l += bad ? __builtin_nanf("") : lse - z[bad ? 0 : y];
         if (dlogits)
             for (int j = 0; j < C; ++j)
-                dlogits[(long)b * C + j] = coef * (expf(z[j] - lse) - (j == y ? 1.f : 0.f)) / (float)B;
+                dlogits[(long)b * C + j] = bad ? __builtin_nanf("") : coef * (expf(z[j] - lse) - (j == y ? 1.f : 0.f)) / (float)B;
     }
     l = block_sum(l, sh);
     if (threadIdx.x == 0) loss[0] = l / (float)B;

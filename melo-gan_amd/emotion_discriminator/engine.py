@@ -25,7 +25,11 @@ Tensor = torch.Tensor
 class EdEngine:
     """One replica of the emotion discriminator's training state on one GPU (input_mode == 'notes')."""
 
-    def __init__(self, cfg: dict, device="cuda", batch_size: Optional[int] = None, max_notes: Optional[int] = None):
+    def __init__(self, cfg: dict, device="cuda", batch_size: Optional[int] = None, max_notes: Optional[int] = None,
+                 share: Optional["EdEngine"] = None):
+        """share: another EdEngine whose parameters, optimiser state, BatchNorm buffers and Philox counter this one
+        uses as its own -- the same model at a different batch size (the trailing partial batch of an epoch: the
+        reference's loaders have no drop_last, ed_dataset.py:542-558)."""
         if cfg.get("input_mode", "latent") != "notes":
             raise ValueError("EdEngine: only input_mode='notes' (the convolutional encoder) is pre-trained here")
         self.cfg = cfg
@@ -41,10 +45,15 @@ class EdEngine:
         self.weight_decay = float(opt.get("weight_decay", 0.0))
         self.decoupled = str(opt.get("name", "adamw")).lower() == "adamw"
         spec, bufs, chans = emotion_disc_spec(cfg)
-        self.P = FlatParams(spec, d)
-        self.buf: Dict[str, Tensor] = OrderedDict()
-        for k, s in bufs.items():
-            self.buf[k] = torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d)
+        if share is not None:
+            if share.P.spec != spec:
+                raise ValueError("EdEngine(share=...): the two engines must have the same model configuration")
+            self.P, self.buf = share.P, share.buf
+        else:
+            self.P = FlatParams(spec, d)
+            self.buf: Dict[str, Tensor] = OrderedDict()
+            for k, s in bufs.items():
+                self.buf[k] = torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d)
         self.chans = chans
         self.mlp = tuple(cfg.get("mlp_hidden", (256, 128)))
         hid = cfg.get("notes_hidden", 256)
@@ -65,10 +74,11 @@ class EdEngine:
         self.dmask = [torch.ones(B, h, device=d) for h in self.mlp]      # keep-mask / (1 - p)
         self.logits, self.dlogits = f(B, self.n_classes), f(B, self.n_classes)
         self.loss = torch.zeros(1, device=d)
-        self.rng_step = torch.zeros(1, dtype=torch.int64, device=d)
+        self.rng_step = share.rng_step if share is not None else torch.zeros(1, dtype=torch.int64, device=d)
         self.rng_seed = int(cfg.get("seed", 42))
-        self.stream = torch.cuda.Stream(device=d)
+        self.stream = share.stream if share is not None else torch.cuda.Stream(device=d)
         self._graphs = {}
+        self._tails: Dict[int, "EdEngine"] = {}
 
     # ---- state in / out ---------------------------------------------------------------------------------
     def init_weights(self, seed: int = 42):
@@ -86,10 +96,24 @@ class EdEngine:
             v.fill_(1.0 if k.endswith("running_var") else 0.0)
 
     def set_lr(self, lr: float):
-        """ReduceLROnPlateau: the learning rate is a launch argument baked into the captured update graph."""
+        """ReduceLROnPlateau: the learning rate is a launch argument of the AdamW kernel, baked into every captured
+        graph that contains the update ('update', 'update#ticked' and the one-graph training step 'step_rng'): those
+        are dropped and re-captured with the new rate on their next run.  Engines sharing this one's parameters
+        (tail()) follow."""
         self.lr = float(lr)
-        for k in [k for k in self._graphs if k.startswith("update")]:
+        for k in [k for k in self._graphs if k.startswith("update") or k == "step_rng"]:
             del self._graphs[k]
+        for t in self._tails.values():
+            t.set_lr(lr)
+
+    def tail(self, rows: int) -> "EdEngine":
+        """The same model (shared parameters / optimiser state / buffers) at a batch of `rows` < B samples."""
+        if not 0 < rows < self.B:
+            raise ValueError(f"tail: rows={rows} must be in (0, {self.B})")
+        if rows not in self._tails:
+            self._tails[rows] = EdEngine(self.cfg, self.dev, rows, self.T, share=self)
+            self._tails[rows].lr = self.lr
+        return self._tails[rows]
 
     def load_state(self, params: Dict[str, Tensor], buffers: Optional[Dict[str, Tensor]] = None):
         self.P.load(params)

@@ -6,9 +6,10 @@ ReduceLROnPlateau, best / periodic checkpoints {"epoch","model","optimizer","cfg
     python -m melo_gan_amd.emotion_discriminator.train_ed --config config/ed_config.yaml
 
 Data: the row-aligned arrays the GAN trainer already uses, `<splits_dir>/<stem of {split}_split_csv>/{notes,emotion}.npy`
-(kept resident in HBM); the reference's per-file manifest/.npz loader (ed_dataset.py) is out of scope.  Batches are
-fixed-size (a trailing partial batch is dropped: every step is a replayed hipGraph).  --synthetic N trains on N random
-rolls (smoke runs without the git-ignored dataset).  input_mode must be 'notes'.
+(kept resident in HBM); the reference's per-file manifest/.npz loader (ed_dataset.py) is out of scope.  Like the
+reference's loaders (no drop_last, ed_dataset.py:542-558) an epoch ends with the trailing partial batch, run by a second
+engine of that batch size over the same parameters (EdEngine.tail); metrics are sample-weighted (train_ed.py:75-82).
+--synthetic N trains on N random rolls (smoke runs without the git-ignored dataset).  input_mode must be 'notes'.
 """
 import argparse
 import os
@@ -19,7 +20,7 @@ import torch
 
 from .. import ops
 from ..gan import config as C
-from ..gan.utils import emotion_to_index, seed_everything
+from ..gan.utils import check_labels, emotion_to_index, seed_everything
 from .engine import EdEngine
 
 
@@ -53,7 +54,8 @@ def load_split(cfg: dict, split: str, device):
         raise FileNotFoundError(f"{paths}: export the split to notes.npy / emotion.npy (the per-file .npz loader of the "
                                 "reference is not implemented)")
     notes = torch.from_numpy(np.ascontiguousarray(np.load(paths[0]), dtype=np.float32)).to(device)
-    labels = torch.tensor([emotion_to_index(e) for e in np.load(paths[1], allow_pickle=True)], dtype=torch.int64, device=device)
+    labels = check_labels(torch.tensor([emotion_to_index(e) for e in np.load(paths[1], allow_pickle=True)], dtype=torch.int64),
+                          int(cfg.get("n_classes", 4)), f"{split} split labels").to(device)
     return notes, labels
 
 
@@ -70,20 +72,23 @@ def synthetic_split(n, T, Cn, seed, device):
 def run_epoch(eng: EdEngine, x, y, train: bool, use_graph: bool, gen=None):
     """train_ed.py:51-82: sample-weighted mean loss and accuracy of one pass; one device->host read per epoch."""
     n, B = x.shape[0], eng.B
+    if n == 0:
+        raise ValueError("run_epoch: the split is empty")
     perm = torch.randperm(n, generator=gen).to(x.device) if train else torch.arange(n, device=x.device)
     acc = torch.zeros(2, device=x.device)
-    steps = n // B
-    for i in range(steps):
-        idx = perm[i * B:(i + 1) * B]
-        eng.set_batch(x.index_select(0, idx), y.index_select(0, idx))
+    for lo in range(0, n, B):
+        rows = min(B, n - lo)
+        e = eng if rows == B else eng.tail(rows)          # trailing partial batch: same parameters, smaller batch
+        idx = perm[lo:lo + rows]
+        e.set_batch(x.index_select(0, idx), y.index_select(0, idx))
         if train:
-            eng.run("step_rng", use_graph)
+            e.run("step_rng", use_graph)
         else:
-            eng.run("forward_eval", use_graph)
-            ops.softmax_ce(eng.logits, eng.y, eng.loss, None, 1.0)
-        acc[0:1] += eng.loss
-        acc[1:2] += (eng.logits.argmax(dim=1) == eng.y).float().mean()
-    loss, a = (acc / max(steps, 1)).tolist()
+            e.run("forward_eval", use_graph)
+            ops.softmax_ce(e.logits, e.y, e.loss, None, 1.0)
+        acc[0:1] += e.loss * rows
+        acc[1:2] += (e.logits.argmax(dim=1) == e.y).float().sum()
+    loss, a = (acc / n).tolist()
     return loss, a
 
 

@@ -22,7 +22,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .utils import emotion_to_index
+from .utils import check_labels, emotion_to_index
 
 
 class Batch:
@@ -66,7 +66,8 @@ class GANDataset:
         self.numeric = torch.from_numpy(np.ascontiguousarray(numeric, dtype=np.float32)).to(device)
         self.latent = (torch.from_numpy(np.ascontiguousarray(latent, dtype=np.float32)) if latent is not None
                        else torch.zeros(n, latent_dim)).to(device)
-        self.emot_idx = torch.tensor([emotion_to_index(e) for e in emotions], dtype=torch.int64, device=device)
+        self.emot_idx = check_labels(torch.tensor([emotion_to_index(e) for e in emotions], dtype=torch.int64),
+                                     4, "GANDataset emotions").to(device)
         self._copy_stream = None
 
     @classmethod

@@ -797,37 +797,3 @@ class GanEngine:
         self._g_fwd(self.notes, train=False)
         return self.notes
 
-
-# ------------------------------------------------------------------------------------------
-# smoke check used by __graft_entry__.smoke(): one tiny D-step + G-step against the oracle
-# ------------------------------------------------------------------------------------------
-def smoke_check(B: int = 4, T: int = 32, C: int = 4, verbose: bool = True):
-    import os
-    import sys
-    root = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
-    if root not in sys.path:
-        sys.path.insert(0, root)
-    from oracle import melo_oracle as O          # the checker, never the product path
-    cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
-    S = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
-    eng = GanEngine(cfg, ed_cfg, "cuda", B)
-    eng.load_state(S.PE, S.PG, S.BG, S.PD, S.PED, S.BED)
-    real, numeric, latent, emot = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 7)
-    R = O.step_randoms(B, cfg["NOISE_DIM"], seed=1)
-    eng.set_batch(real.cuda(), numeric.cuda(), latent.cuda(), emot.cuda())
-    eng.set_randoms(R["noise_d"].cuda(), [m.cuda() for m in R["dm_d"]], R["alpha"].cuda())
-    eng.d_backward()
-    eng.d_update()
-    eng.set_randoms(R["noise_g"].cuda(), [m.cuda() for m in R["dm_g"]])
-    eng.g_backward()
-    eng.g_update()
-    torch.cuda.synchronize()
-    rd = O.d_step(S, real, latent, numeric, R["noise_d"], R["alpha"], R["dm_d"])
-    rg = O.g_step(S, latent, numeric, emot, R["noise_g"], R["dm_g"])
-    got = (eng.loss_d_out[0].item(), eng.gp.item(), eng.adv.item(), eng.emo.item())
-    ref = (rd["loss_d"].item(), rd["gp"].item(), rg["loss_g_adv"].item(), rg["loss_g_emo"].item())
-    for g_, r_ in zip(got, ref):
-        assert abs(g_ - r_) <= 1e-4 * max(1.0, abs(r_)), (got, ref)
-    torch.testing.assert_close(eng.notes.cpu(), rg["fake"], rtol=1e-3, atol=1e-5)
-    if verbose:
-        print("smoke ok: loss_d/gp/adv/emo", got, "oracle", ref)

@@ -28,6 +28,18 @@ def weights_init(m):
             torch.nn.init.constant_(m.bias.data, 0.0)
 
 
+def check_labels(idx, n_classes: int = 4, what: str = "emotion labels"):
+    """Class indices must lie in [0, n_classes): the reference's CrossEntropyLoss raises on anything else (and
+    emotion_to_index maps unknown / missing labels to -1).  Raises ValueError naming the first offenders."""
+    t = torch.as_tensor(idx)
+    bad = ((t < 0) | (t >= n_classes)).nonzero().flatten()
+    if bad.numel():
+        rows = bad[:8].tolist()
+        raise ValueError(f"{what}: {bad.numel()} of {t.numel()} outside [0, {n_classes}) -- first rows {rows}, "
+                         f"values {t.flatten()[bad[:8]].tolist()} (unknown emotion names map to -1)")
+    return t
+
+
 def emotion_to_index(emotion):
     """utils.py:63-73."""
     if emotion is None:

@@ -3,9 +3,10 @@
 Restates /root/reference/src/gan/utils.py:13-28,95-161 (save_piano_roll_to_midi: scale snapping, rests below the
 velocity threshold, duration/step in beats, bpm clamp) and /root/reference/tools/roll_to_midi.py:1-25.  The NOTE
 EVENTS are pinned against the reference function (tests/golden/midi_events.npz, tests/test_midi.py); the byte
-serialisation follows pretty_midi's documented layout -- SMF format 1, division 220, track 0 = tempo + 4/4 time
-signature, track 1 = program change + note-on / note-on-velocity-0 pairs -- but is NOT pinned byte-for-byte
-(pretty_midi is not installable here): parity unpinned for the serialisation only.
+serialisation -- SMF format 1, division 220, track 0 = tempo + 4/4 time signature, track 1 = program change +
+note-on / note-on-velocity-0 pairs in pretty_midi's event order, running status -- is pinned against .mid files the
+reference itself commits (good_gens1/*.mid, copied as data to tests/golden/ref_mid/): parsed to tick events and
+written back, write_smf_ticks reproduces them byte for byte.
 """
 from __future__ import annotations
 
@@ -64,28 +65,39 @@ def _vlq(n: int) -> bytes:
     return bytes(reversed(b))
 
 
-def write_smf(path: str, notes: Sequence[Note], bpm: float = 120.0, program: int = 0) -> None:
-    """Format-1 SMF: meta track (set_tempo, 4/4) + one instrument track on channel 0."""
-    tick = lambda sec: int(round(sec * bpm / 60.0 * RESOLUTION))  # noqa: E731
-    ev = []
-    for vel, pitch, start, end in notes:
-        ev.append((tick(start), 1, pitch, vel))
-        ev.append((tick(end), 0, pitch, 0))            # note-on with velocity 0 == note-off (pretty_midi's form)
-    ev.sort(key=lambda e: (e[0], e[1], e[2]))           # at equal ticks: offs before ons
-    last = max((e[0] for e in ev), default=0)
-    tempo = int(round(6e7 / bpm))
-    t0 = b"\x00\xff\x51\x03" + struct.pack(">I", tempo)[1:] + b"\x00\xff\x58\x04\x04\x02\x18\x08"
-    t0 += _vlq(last + 1) + b"\xff\x2f\x00"
+def write_smf_ticks(path: str, events: Sequence[Tuple[int, int, int]], tempo_us: int = 500000, program: int = 0) -> None:
+    """Format-1 SMF from tick-level events (tick, pitch, velocity; velocity 0 = note-off), byte for byte the file
+    pretty_midi 0.2.x / mido write for one instrument (pinned by tests/test_midi.py against .mid files the reference
+    commits under good_gens1/): track 0 = set_tempo, 4/4 time signature, end_of_track at tick 1; track 1 = program
+    change, the note events sorted by (tick, pitch * 256 + velocity) -- pretty_midi's event_compare, where a note-off is a
+    note-on of velocity 0 -- written with MIDI running status, end_of_track one tick after the last event."""
+    ev = sorted(events, key=lambda e: (e[0], e[1] * 256 + e[2]))
+    t0 = b"\x00\xff\x51\x03" + struct.pack(">I", tempo_us)[1:] + b"\x00\xff\x58\x04\x04\x02\x18\x08"
+    t0 += _vlq(1) + b"\xff\x2f\x00"
     t1 = b"\x00" + bytes([0xC0, program & 0x7F])
-    cur = 0
-    for tk, _, pitch, vel in ev:
-        t1 += _vlq(tk - cur) + bytes([0x90, pitch & 0x7F, vel & 0x7F])
+    cur, status = 0, None
+    for tk, pitch, vel in ev:
+        t1 += _vlq(tk - cur)
+        if status != 0x90:
+            t1 += b"\x90"
+            status = 0x90
+        t1 += bytes([pitch & 0x7F, vel & 0x7F])
         cur = tk
     t1 += _vlq(1) + b"\xff\x2f\x00"
     with open(path, "wb") as f:
         f.write(b"MThd" + struct.pack(">IHHH", 6, 1, 2, RESOLUTION))
         for trk in (t0, t1):
             f.write(b"MTrk" + struct.pack(">I", len(trk)) + trk)
+
+
+def write_smf(path: str, notes: Sequence[Note], bpm: float = 120.0, program: int = 0) -> None:
+    """Notes in seconds -> ticks at `bpm` (pretty_midi's time_to_tick for a single tempo) -> write_smf_ticks."""
+    tick = lambda sec: int(round(sec * bpm / 60.0 * RESOLUTION))  # noqa: E731
+    ev = []
+    for vel, pitch, start, end in notes:
+        ev.append((tick(start), pitch, vel))
+        ev.append((tick(end), pitch, 0))               # note-on with velocity 0 == note-off (pretty_midi's form)
+    write_smf_ticks(path, ev, int(round(6e7 / bpm)), program)
 
 
 def save_piano_roll_to_midi(notes_array, output_path, fs=100, bpm=120.0, scale="major", root_key=0,
@@ -110,16 +122,39 @@ def roll_to_midi(roll, output_path="generated_sample.mid"):
     print("Wrote", output_path)
 
 
-def read_smf_notes(path: str):
-    """Minimal parser of the files write_smf produces (tests): returns (division, tempo_us, [(tick_on, tick_off, pitch, vel)])."""
+def notes_from_ae_rows(notes_arr) -> List[Note]:
+    """/root/reference/src/ae/midi_utils.py:12-35 (notes_array_to_prettymidi): rows (pitch, start, duration, velocity) in
+    MIDI units / seconds; rows with pitch <= 0 or duration <= 0 are padding; pitch and velocity rounded and clipped."""
+    out = []
+    for p, s, d, v in np.asarray(notes_arr):
+        if p <= 0 or d <= 0:
+            continue
+        out.append((int(np.clip(round(float(v)), 1, 127)), int(np.clip(round(float(p)), 0, 127)), float(s), float(s + d)))
+    return out
+
+
+def save_recon_midi(notes_in, notes_out, outdir: str, prefix: str, tempo: float = 120.0):
+    """/root/reference/src/ae/midi_utils.py:37-47: <outdir>/<prefix>_in.mid and <prefix>_out.mid (the VAE trainer's
+    per-epoch reconstruction dump, train_ae.py:173-188)."""
+    import os
+    os.makedirs(outdir, exist_ok=True)
+    for arr, tag in ((notes_in, "in"), (notes_out, "out")):
+        # pretty_midi refuses negative times; a (normalised) reconstruction may carry them -- clamp like roll_to_midi does
+        notes = [(v, p, max(0.0, s), max(0.0, e)) for v, p, s, e in notes_from_ae_rows(arr)]
+        write_smf(os.path.join(outdir, f"{prefix}_{tag}.mid"), notes, tempo, 0)
+
+
+def read_smf_events(path: str):
+    """Parser of the files write_smf_ticks / pretty_midi produce (format 1, one tempo, note-ons only, running status):
+    returns ((format, division), tempo_us, program, [(tick, pitch, velocity)] of track 1 in file order)."""
     data = open(path, "rb").read()
     assert data[:4] == b"MThd"
     _, fmt, ntrk, div = struct.unpack(">IHHH", data[4:14])
-    pos, tempo, notes = 14, None, []
+    pos, tempo, program, events = 14, None, None, []
     for _ in range(ntrk):
         assert data[pos:pos + 4] == b"MTrk"
         ln = struct.unpack(">I", data[pos + 4:pos + 8])[0]
-        trk, p, tk, on = data[pos + 8:pos + 8 + ln], 0, 0, {}
+        trk, p, tk, status = data[pos + 8:pos + 8 + ln], 0, 0, None
         pos += 8 + ln
         while p < len(trk):
             d = 0
@@ -129,22 +164,38 @@ def read_smf_notes(path: str):
                 if not c & 0x80:
                     break
             tk += d
-            st = trk[p]
-            if st == 0xFF:
+            if trk[p] == 0xFF:
                 mt, n = trk[p + 1], trk[p + 2]
                 if mt == 0x51:
                     tempo = int.from_bytes(trk[p + 3:p + 6], "big")
                 p += 3 + n
-            elif st & 0xF0 == 0xC0:
+                status = None
+                continue
+            if trk[p] & 0x80:
+                status = trk[p]
+                p += 1
+            if status is None:
+                raise ValueError("data byte without a running status")
+            if status & 0xF0 == 0xC0:
+                program = trk[p]
+                p += 1
+            elif status & 0xF0 == 0x90:
+                events.append((tk, trk[p], trk[p + 1]))
                 p += 2
-            elif st & 0xF0 == 0x90:
-                pitch, vel = trk[p + 1], trk[p + 2]
-                p += 3
-                if vel:
-                    on.setdefault(pitch, []).append((tk, vel))
-                else:
-                    t_on, v = on[pitch].pop(0)
-                    notes.append((t_on, tk, pitch, v))
             else:
-                raise ValueError(f"unexpected status {st:#x}")
-    return (fmt, div), tempo, sorted(notes)
+                raise ValueError(f"unexpected status {status:#x}")
+    return (fmt, div), tempo, program, events
+
+
+def read_smf_notes(path: str):
+    """returns ((format, division), tempo_us, [(tick_on, tick_off, pitch, vel)]): note-ons paired first-in-first-out with
+    the note-offs of their pitch."""
+    hdr, tempo, _, events = read_smf_events(path)
+    on, notes = {}, []
+    for tk, pitch, vel in events:
+        if vel:
+            on.setdefault(pitch, []).append((tk, vel))
+        else:
+            t_on, v = on[pitch].pop(0)
+            notes.append((t_on, tk, pitch, v))
+    return hdr, tempo, sorted(notes)

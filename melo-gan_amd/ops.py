@@ -245,16 +245,23 @@ def linear_dgrad(dy, w, dx, **epi):
 # weight gradients
 # ---------------------------------------------------------------------------------------
 _ws_cache = {}
+_ws_retired = []      # superseded scratch buffers: never freed, a captured hipGraph may still hold their address
 
 
 def workspace(nbytes: int, device, tag: str = "default") -> Tensor:
     """Grow-only scratch buffer per (device, tag, current stream) -- launches that may run concurrently on
-    different streams never share scratch.  Allocation happens outside graph capture because every engine
-    warms up eagerly (same stream assignment) before capturing."""
+    different streams never share scratch.  A buffer that has to grow is REPLACED, and the old one is kept alive for
+    the life of the process: a hipGraph captured earlier has its address baked in and would otherwise replay into
+    memory the caching allocator has handed to someone else (sub-steps are captured one by one, each after its own
+    eager warm-up, so a later sub-step may ask for more than the graphs captured before it saw).  Growth is geometric,
+    so the retired buffers of a tag add up to less than its final size."""
     key = (str(device), tag, torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _ws_retired.append(buf)
+        size = max(nbytes, 1 << 20, 2 * buf.numel() if buf is not None else 0)
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 

@@ -391,7 +391,71 @@ def midi_case(name):
     print(name, {k: v.shape for k, v in out.items() if k.endswith("notes")})
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ed_train":     # only the f-2 fixtures
+def install_midi_recorder(rec):
+    """Recording stand-ins for the four pretty_midi names save_piano_roll_to_midi uses (pretty_midi is absent)."""
+    class Note:
+        def __init__(self, velocity, pitch, start, end):
+            self.velocity, self.pitch, self.start, self.end = velocity, pitch, start, end
+
+    class Instrument:
+        def __init__(self, program):
+            self.program, self.notes = program, []
+
+    class PrettyMIDI:
+        def __init__(self, initial_tempo=120.0):
+            rec["tempo"] = initial_tempo
+            self.instruments = []
+
+        def write(self, path):
+            rec["notes"] = [(n.velocity, n.pitch, n.start, n.end) for n in self.instruments[0].notes]
+            rec["program"] = self.instruments[0].program
+
+    pm = sys.modules["pretty_midi"]
+    pm.Note, pm.Instrument, pm.PrettyMIDI = Note, Instrument, PrettyMIDI
+    pm.instrument_name_to_program = lambda nm: {"Acoustic Grand Piano": 0, "Violin": 40}[nm]
+
+
+def gen1_case(name, T, C, g_scale=4.0, last_scale=400.0):
+    """BASELINE config 5 / app.py:92-119: batch-1 generation, E_num -> G in eval mode (dropout off, BatchNorm on
+    NON-trivial running statistics), at the reference's own shape (T=512, C=4) and at the 128x256 roll.  Generator
+    weights are the closed-form fill x g_scale so that the output spans the MIDI writer's branches; for C=4 the note
+    events the reference's save_piano_roll_to_midi derives from the generated roll are recorded too."""
+    cfg, ed_cfg = O.default_gan_cfg(1, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "closed_form")
+    for k in S.PG:
+        if k.endswith("weight") and S.PG[k].dim() > 1:
+            S.PG[k].mul_(g_scale * (last_scale if k == "decoder.deconv.6.weight" else 1.0))
+    S.BG.update(O.fill_buffers(O.generator_buffers(), 70.0))
+    z = O.closed_form((1, cfg["NOISE_DIM"]), 13.0, 1.0)
+    numeric = O.closed_form((1, 6), 17.0, 1.0)
+    # centre every output channel (the last layer's bias is recorded in the fixture: not closed-form)
+    S.PG["decoder.deconv.6.bias"].zero_()
+    E, G, _, _ = build_reference(cfg, ed_cfg, S)
+    G.eval(); E.eval()
+    with torch.no_grad():
+        S.PG["decoder.deconv.6.bias"].copy_(-G(z, None, E(numeric))[0][0].mean(0))
+    E, G, _, _ = build_reference(cfg, ed_cfg, S)
+    G.eval(); E.eval()
+    with torch.no_grad():
+        emb = E(numeric)
+        gen, lat = G(z, None, emb)
+    out = dict(bias6=S.PG["decoder.deconv.6.bias"].numpy().copy(), B=1, T=T, C=C, g_scale=g_scale, last_scale=last_scale, emb=emb.numpy().copy(), generated=gen.numpy().copy(), latent=lat.numpy().copy())
+    if C == 4:
+        rec = {}
+        install_midi_recorder(rec)
+        from src.gan.utils import save_piano_roll_to_midi
+        save_piano_roll_to_midi(gen[0].numpy(), "/dev/null", bpm=100.0, scale="minor", root_key=2)
+        out["notes"] = np.array(rec["notes"], dtype=np.float64)
+        out["tempo"] = np.float64(rec["tempo"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "generated", tuple(gen.shape), "min/max", float(gen.min()), float(gen.max()),
+          "notes", out.get("notes", np.zeros((0, 4))).shape)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gen1":           # only the cfg5 fixtures
+    gen1_case("gen1_c4_t512", 512, 4)
+    gen1_case("gen1_c128_t256", 256, 128)
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ed_train":     # only the f-2 fixtures
     ed_train_case("ed_train_c4_t32_b8", 8, 32, 4)
     ed_train_case("ed_train_c128_t16_b4", 4, 16, 128, n_steps=2)
 elif __name__ == "__main__":
@@ -406,3 +470,5 @@ elif __name__ == "__main__":
     midi_case("midi_events")
     ed_train_case("ed_train_c4_t32_b8", 8, 32, 4)
     ed_train_case("ed_train_c128_t16_b4", 4, 16, 128, n_steps=2)
+    gen1_case("gen1_c4_t512", 512, 4)
+    gen1_case("gen1_c128_t256", 256, 128)

@@ -133,3 +133,86 @@ def test_ed_trainer_cli_smoke_and_checkpoint_feeds_the_gan_trainer(tmp_path):
     for k in gan.ED.spec:
         assert torch.equal(gan.ED.p[k].cpu(), ck["model"][k]), k
     assert torch.equal(gan.EDbuf["encoder.conv.0.net.1.running_var"].cpu(), ck["model"]["encoder.conv.0.net.1.running_var"])
+
+
+def test_set_lr_reaches_the_one_graph_training_step():
+    """ReduceLROnPlateau (train_ed.py:101-123) under graph replay: the learning rate is baked into the captured
+    'step_rng' graph, so set_lr must drop it -- with lr = 0 a replayed step must leave every parameter untouched."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.emotion_discriminator.engine import EdEngine
+    cfg = dict(O.default_ed_cfg(4), dropout=0.2, optimizer=dict(name="AdamW", lr=1e-3, betas=[0.5, 0.999], weight_decay=0.0))
+    eng = EdEngine(cfg, "cuda", 8, 32)
+    _, spec, P, Bf = initial_state(4)
+    eng.load_state(P, Bf)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(8, 32, 4, generator=gen) * 2 - 1).cuda()
+    y = torch.randint(0, 4, (8,), generator=gen).cuda()
+    with torch.cuda.stream(eng.stream):
+        eng.set_batch(x, y)
+        for _ in range(3):                       # eager warm-up, capture, replay
+            eng.run("step_rng")
+        torch.cuda.synchronize()
+        assert not isinstance(eng._graphs["step_rng"], str)
+        before = eng.P.data.clone()
+        eng.run("step_rng")
+        torch.cuda.synchronize()
+        assert not torch.equal(before, eng.P.data)           # lr 1e-3: the replayed step moves the parameters
+        eng.set_lr(0.0)
+        assert "step_rng" not in eng._graphs
+        before = eng.P.data.clone()
+        for _ in range(3):                       # eager, capture, replay -- all with lr = 0
+            eng.run("step_rng")
+        torch.cuda.synchronize()
+        assert torch.equal(before, eng.P.data)
+    assert float(eng.P.state[0].item()) == 7.0
+
+
+def test_epoch_includes_the_trailing_partial_batch():
+    """The reference's ED loaders have no drop_last and weight each batch by its size (ed_dataset.py:542-558,
+    train_ed.py:75-82): an epoch over n = 2B + 3 samples evaluates all of them, n < B does not report 0.0, and a
+    training epoch takes ceil(n / B) optimiser steps."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.emotion_discriminator import train_ed
+    from melo_gan_amd.emotion_discriminator.engine import EdEngine
+    B, T, C = 8, 32, 4
+    cfg = dict(O.default_ed_cfg(C), dropout=0.2, optimizer=dict(name="AdamW", lr=1e-3, betas=[0.5, 0.999], weight_decay=0.0))
+    ed_cfg, spec, P, Bf = initial_state(C)
+    eng = EdEngine(cfg, "cuda", B, T)
+    eng.load_state(P, Bf)
+    gen = torch.Generator().manual_seed(11)
+    for n in (2 * B + 3, 3):
+        x = torch.rand(n, T, C, generator=gen) * 2 - 1
+        y = torch.randint(0, 4, (n,), generator=gen)
+        with torch.no_grad():
+            logits = O.emotion_disc_fwd(P, Bf, x, ed_cfg, False, None)
+            ref_loss = torch.nn.functional.cross_entropy(logits, y).item()
+            ref_acc = (logits.argmax(1) == y).float().mean().item()
+        with torch.cuda.stream(eng.stream):
+            loss, acc = train_ed.run_epoch(eng, x.cuda(), y.cuda(), False, True)
+            loss2, acc2 = train_ed.run_epoch(eng, x.cuda(), y.cuda(), False, True)     # second pass: graphs
+        assert abs(loss - ref_loss) < 2e-5 and abs(acc - ref_acc) < 1e-6, (n, loss, ref_loss, acc, ref_acc)
+        assert loss2 == loss and acc2 == acc
+    steps0 = float(eng.P.state[0].item())
+    with torch.cuda.stream(eng.stream):
+        train_ed.run_epoch(eng, x.cuda(), y.cuda(), True, True, torch.Generator().manual_seed(0))
+        x19 = (torch.rand(19, T, C, generator=gen) * 2 - 1).cuda()
+        train_ed.run_epoch(eng, x19, torch.randint(0, 4, (19,), generator=gen).cuda(), True, True, torch.Generator().manual_seed(0))
+    assert float(eng.P.state[0].item()) == steps0 + 1 + 3
+    with pytest.raises(ValueError):
+        train_ed.run_epoch(eng, x.cuda()[:0], y.cuda()[:0], False, True)
+
+
+def test_out_of_range_label_poisons_the_loss_instead_of_reading_out_of_bounds():
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    from melo_gan_amd.gan.utils import check_labels
+    logits = torch.randn(6, 4, device="cuda")
+    loss, dl = torch.zeros(1, device="cuda"), torch.zeros(6, 4, device="cuda")
+    for bad in (-1, 4):
+        y = torch.tensor([0, 1, 2, 3, bad, 1], device="cuda")
+        ops.softmax_ce(logits, y, loss, dl, 1.0)
+        assert torch.isnan(loss).all() and torch.isnan(dl[4]).all() and torch.isfinite(dl[:4]).all()
+        with pytest.raises(ValueError, match="outside"):
+            check_labels(y.cpu(), 4)
+    ops.softmax_ce(logits, torch.tensor([0, 1, 2, 3, 3, 1], device="cuda"), loss, dl, 1.0)
+    assert torch.isfinite(loss).all()

@@ -255,4 +255,40 @@ def test_production_flow_is_bitwise_reproducible_and_matches_the_dp_flow(engine_
 
 
 def test_smoke_entry(engine_mod):
-    engine_mod.smoke_check(verbose=False)
+    import __graft_entry__ as entry
+    entry.smoke_check(verbose=False)
+
+
+def test_workspaces_outlive_the_graphs_that_captured_them(engine_mod):
+    """The trainer's default shape (B=32, T=512, C=4) with CRITIC_ITERS > 1: the critic step is captured several batches
+    before the generator step first runs and asks for a larger 'wgrad_multi' scratch buffer.  The superseded buffer has
+    its address baked into the critic graph: it must stay allocated (ops._ws_retired), and the replayed critic graph
+    must keep matching an engine that never replays."""
+    from melo_gan_amd import ops
+    cfg, ed_cfg = O.default_gan_cfg(32, 512, 4), O.default_ed_cfg(4)
+    engines = []
+    for _ in range(2):
+        e = engine_mod.GanEngine(cfg, ed_cfg, "cuda", 32)
+        e.init_weights(3)
+        e.seed(5)
+        engines.append(e)
+    real, numeric, latent, emot = O.synthetic_batch(32, 512, 4, cfg["LATENT_DIM"], 6, 1)
+    e_graph, e_eager = engines
+    key = lambda: (str(e_graph.dev), "wgrad_multi", e_graph.stream.cuda_stream)  # noqa: E731
+    with torch.cuda.stream(e_graph.stream):
+        for e in engines:
+            e.set_batch(real.cuda(), numeric.cuda(), latent.cuda(), emot.cuda())
+        ptrs = []
+        for it in range(10):
+            for e, graph in ((e_graph, True), (e_eager, False)):
+                e.run("d_step_rng", graph)
+                if it % 5 == 4:
+                    e.run("g_step_rng", graph)
+            if it == 2:                                   # critic graph exists, the generator step has not run yet
+                assert not isinstance(e_graph._graphs["d_step_rng"], str) and "g_step_rng" not in e_graph._graphs
+                ptrs.append(ops._ws_cache[key()].data_ptr())
+        torch.cuda.synchronize()
+    now = ops._ws_cache[key()].data_ptr()
+    if now != ptrs[0]:                                    # the buffer grew: the captured one must still be alive
+        assert any(b.data_ptr() == ptrs[0] for b in ops._ws_retired)
+    assert torch.equal(e_graph.D.data, e_eager.D.data) and torch.equal(e_graph.GE.data, e_eager.GE.data)

@@ -209,3 +209,38 @@ def test_ed_pretraining_steps_match_reference(name):
             assert close_ck(ck, ref, 2e-4), (k, ck, ref)
     logits = O.emotion_disc_fwd(P, Bf, torch.from_numpy(g["s0.x"]), ed_cfg)
     np.testing.assert_allclose(logits.numpy(), g["end.eval_logits"], rtol=1e-3, atol=1e-4)
+
+
+def gen1_state(g):
+    """The state tests/golden/make_golden.py::gen1_case builds (closed-form fill, generator weights x g_scale, last
+    deconvolution x last_scale with the recorded bias, non-trivial BatchNorm running statistics)."""
+    T, C = int(g["T"]), int(g["C"])
+    cfg, ed_cfg = O.default_gan_cfg(1, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "closed_form")
+    for k in S.PG:
+        if k.endswith("weight") and S.PG[k].dim() > 1:
+            S.PG[k].mul_(float(g["g_scale"]) * (float(g["last_scale"]) if k == "decoder.deconv.6.weight" else 1.0))
+    S.PG["decoder.deconv.6.bias"].copy_(torch.from_numpy(g["bias6"]))
+    S.BG.update(O.fill_buffers(O.generator_buffers(), 70.0))
+    return S, cfg, O.closed_form((1, cfg["NOISE_DIM"]), 13.0, 1.0), O.closed_form((1, 6), 17.0, 1.0)
+
+
+@pytest.mark.parametrize("name", ["gen1_c4_t512", "gen1_c128_t256"])
+def test_batch1_generation_matches_reference(name):
+    """BASELINE config 5 (app.py:92-119): E_num -> G, eval mode, B = 1."""
+    g = load(name)
+    S, cfg, z, numeric = gen1_state(g)
+    with torch.no_grad():
+        emb = O.feature_encoder_fwd(S.PE, numeric, None)
+        gen, lat = O.generator_fwd(S.PG, S.BG, z, None, emb, cfg["INTEGRATION_MODE"], cfg["MAX_NOTES"], train=False)
+    np.testing.assert_allclose(emb.numpy(), g["emb"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(lat.numpy(), g["latent"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(gen.numpy(), g["generated"], rtol=1e-4, atol=2e-6)
+    if "notes" in g.files:          # ... and through the output contract (the MIDI note events of that roll)
+        import melo_gan_amd  # noqa: F401
+        from melo_gan_amd import midi
+        notes, bpm = midi.notes_from_roll(g["generated"][0], bpm=100.0, scale="minor", root_key=2)
+        assert bpm == float(g["tempo"]) and len(notes) == len(g["notes"])
+        got = np.array(notes, dtype=np.float64)
+        assert np.array_equal(got[:, :2], g["notes"][:, :2])
+        np.testing.assert_allclose(got[:, 2:], g["notes"][:, 2:], rtol=0, atol=1e-9)
