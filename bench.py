@@ -8,7 +8,10 @@ Melo-GAN's GAN training hot path (G + D + frozen emotion-D), B=64 per GPU, 128x2
 
 A "step" = one D-step (src/gan/train_gan.py:183-205) + one G-step (:211-251) on one batch of
 synthetic (B, T=256, C=128) rolls resident in HBM, including the per-step device RNG draws,
-the gradient all-reduce (N>1) and both Adam updates.  value = N*B*K / max-over-ranks wall time.
+the gradient all-reduce (N>1) and both Adam updates.  value = N*B*K / max-over-ranks wall time of
+exactly K steps (barrier + synchronize on both sides).  Beside it, "event_timing": every step of a
+second window of max(K, 64) steps between its own pair of HIP events on the engine's stream --
+median / p10 / p90 per step (median of >= 50 hipEvent-timed iterations).
 
 The same JSON line carries
   roofline     : the dominant kernel SYMBOL (stride-1 K=3 64x64-tile window-GEMM: ED conv1-3 forward and their
@@ -16,7 +19,8 @@ The same JSON line carries
                  one step and replayed (same tensors, one hipGraph, HIP events on the launch stream): algorithmic
                  FLOPs / that time, against the dense fp32-MFMA peak (157.3 TFLOP/s);
   cpu_baseline : the oracle (PyTorch-CPU fp32 restatement of the reference step) timed on this
-                 host's cores on a bounded number of the same steps (rank 0, N=1 only).
+                 host on a bounded number of the same steps (rank 0, N=1 only): once with every physical
+                 core this process may use, once with 1 thread; CPU model and counts stated.
 """
 import argparse
 import json
@@ -42,13 +46,16 @@ MFLOP_PER_SAMPLE = 889.6
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the all-cores CPU leg (the 1-thread "
+                    "leg gets the same budget and at least 2 steps)")
     ap.add_argument("--profile-steps", type=int, default=20,
                     help="replays of the dominant kernel's launches (one step's worth each) for the roofline leg; 0 = skip")
+    ap.add_argument("--launch-flops", default=None, metavar="FILE",
+                    help="write {kernel symbol: launches and GFLOP per step} of one eager step to FILE (tools/pmc_mfma_busy.py)")
     ap.add_argument("--workload", default="gan", choices=["gan", "ae", "gen1", "ed"],
                     help="gan: the headline cfg2 step (default); ae: BASELINE config 4 (VAE step, B=256, T=256, C=4); "
                          "gen1: BASELINE config 5 (batch-1 E_num->G generation latency); ed: emotion-discriminator "
@@ -99,25 +106,47 @@ def time_dominant(ops, records, reps):
     return sum(a.elapsed_ms(b) for a, b in pairs)
 
 
-def host_cores() -> int:
-    """CPU threads this process may actually use: the cgroup quota if there is one, else the affinity mask,
-    capped at 16 (the GPU box's CPU share per GPU) -- oversubscribing ATen's thread pool is far slower."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def host_cpu():
+    """(threads to use, physical cores of the host, logical CPUs this process may run on, model name).  Threads = the
+    physical cores this process can actually use: logical CPUs of the affinity mask, limited by a cgroup CPU quota if
+    there is one, and never more than one thread per physical core (ATen's CPU kernels lose with SMT siblings)."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    phys = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":", 1)[1].strip()
+                elif not ln.strip():
+                    if core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    physical = len(cores) or logical
+    n = min(logical, physical)
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
             quota, period = f.read().split()
             if quota != "max":
                 n = min(n, max(1, int(int(quota) / int(period))))
-    except OSError:
+    except (OSError, ValueError):
         pass
-    return max(1, min(n, 16))
+    if os.environ.get("MELO_CPU_THREADS"):
+        n = int(os.environ["MELO_CPU_THREADS"])
+    return max(1, n), physical, logical, model
 
 
 def cpu_baseline(seconds: float):
-    """Oracle (the CPU restatement, pinned to the reference by tests/golden) on the host cores."""
+    """Oracle (the CPU restatement, pinned to the reference by tests/golden) on the host cores: all usable physical
+    cores, then 1 thread.  Bounded: `seconds` per leg (at least 2 timed steps)."""
     from oracle import melo_oracle as O
-    cores = host_cores()
-    torch.set_num_threads(cores)
+    threads, physical, logical, model = host_cpu()
     cfg, ed_cfg = O.default_gan_cfg(B_PER_GPU, T, C), O.default_ed_cfg(C)
     S = O.build_gan_state(cfg, ed_cfg, "weights_init", seed=42)
     real, numeric, latent, emot = O.synthetic_batch(B_PER_GPU, T, C, cfg["LATENT_DIM"], 6, 42)
@@ -127,18 +156,30 @@ def cpu_baseline(seconds: float):
         O.d_step(S, real, latent, numeric, R["noise_d"], R["alpha"], R["dm_d"])
         O.g_step(S, latent, numeric, emot, R["noise_g"], R["dm_g"])
 
-    one(0)
-    one(1)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one(2 + n)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 5000:
-            break
-    return dict(value=round(B_PER_GPU * n / el, 2), unit="samples/s", cores=cores, kind="port",
-                sample=f"{n} full (1D+1G) steps of the same B=64, T=256, C=128 workload, fp32, "
-                       f"torch {torch.__version__} CPU, {el:.1f} s")
+    def leg(nthreads, warm):
+        torch.set_num_threads(nthreads)
+        for i in range(warm):
+            one(i)
+        ts = []
+        t0 = time.perf_counter()
+        while True:
+            t1 = time.perf_counter()
+            one(warm + len(ts))
+            ts.append(time.perf_counter() - t1)
+            if (time.perf_counter() - t0 >= seconds and len(ts) >= 2) or len(ts) >= 5000:
+                break
+        ts.sort()
+        return B_PER_GPU / ts[len(ts) // 2], len(ts), time.perf_counter() - t0
+
+    v_all, n_all, el_all = leg(threads, 2)
+    v_one, n_one, el_one = leg(1, 1)
+    torch.set_num_threads(threads)
+    return dict(value=round(v_all, 2), unit="samples/s", cores=threads, kind="port",
+                sample=f"median of {n_all} full (1D+1G) steps of the same B=64, T=256, C=128 workload, fp32, "
+                       f"torch {torch.__version__} CPU, {threads} threads, {el_all:.1f} s",
+                value_1thread=round(v_one, 2),
+                sample_1thread=f"median of {n_one} steps, 1 thread, {el_one:.1f} s",
+                cpu_model=model, host_physical_cores=physical, usable_logical_cpus=logical)
 
 
 def side_workload(args):
@@ -314,6 +355,26 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True).wait()
             el = float(t.item())
 
+        # ---- per-step HIP events: a second window of >= 64 steps, each between its own event pair on the
+        # engine's stream; the host runs ahead, so the events see device time only ----
+        n_ev = max(args.steps, 64)
+        evs = [ops.Event() for _ in range(n_ev + 1)]
+        evs[0].record()
+        for i in range(n_ev):
+            step(i)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        barrier()
+        per = sorted(evs[i].elapsed_ms(evs[i + 1]) for i in range(n_ev))
+        ev_stats = [per[n_ev // 2], per[n_ev // 10], per[(9 * n_ev) // 10]]
+        if dist_on:      # the slowest rank's median (the ranks are in lock-step through the collectives anyway)
+            t = torch.tensor(ev_stats, device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True).wait()
+            ev_stats = t.tolist()
+        event_timing = {"method": "hipEvent pair per step on the engine stream", "steps": n_ev,
+                        "median_ms": round(ev_stats[0], 4), "p10_ms": round(ev_stats[1], 4), "p90_ms": round(ev_stats[2], 4),
+                        "value_at_median": round(world * B_PER_GPU / (ev_stats[0] * 1e-3), 1)}
+
         # ---- secondary: the reference's schedule, CRITIC_ITERS = 5 critic updates per generator update ----
         sched = None
         if args.profile_steps > 0:
@@ -357,21 +418,31 @@ def main():
                 ms = time_dominant(ops, hook.records, reps)
                 launches = reps * len(hook.records)
                 flops = reps * sum(r[1] for r in hook.records)
-                # HBM bytes per launch of this kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
-                # WRITE_SIZE passes, gfx950 correction applied): measured offline, committed under profiles/
-                traffic = None
-                try:
-                    with open(os.path.join(ROOT, "profiles", "r01_traffic_dominant_kernel.json")) as f:
-                        tj = json.load(f)
-                    if tj.get("kernel") == DOMINANT_NAME:
-                        traffic = round(tj["traffic_bytes_per_launch"])
-                except (OSError, ValueError, KeyError):
-                    pass
+                # HBM bytes per launch need the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+                # passes, tools/pmc_traffic.py): they cannot be read from inside this process, so the field is null here
+                # and the measured figure lives under profiles/ with the command that produced it
                 achieved = flops / (ms * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, kernel=DOMINANT_NAME,
+                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                            traffic_measured_in="profiles/r02_traffic_dominant_kernel.json (separate rocprofv3 --pmc passes)",
+                            kernel=DOMINANT_NAME,
                             launches=launches, avg_us=round(1e3 * ms / launches, 2),
                             avg_gflop_per_launch=round(flops / launches / 1e9, 3))
+        if rank == 0 and args.launch_flops:
+            tally = {}
+
+            def count(symbol, flops, launch=None):
+                t = tally.setdefault(symbol, {"launches_per_step": 0, "gflop_per_step": 0.0})
+                t["launches_per_step"] += 1
+                t["gflop_per_step"] += flops / 1e9
+                return ops._NullCtx()
+            ops.set_launch_hook(count)
+            eng.set_batch(*pool[0])
+            eng.d_backward_rng(); eng.d_update(); eng.g_backward_rng(); eng.g_update()
+            torch.cuda.synchronize()
+            ops.set_launch_hook(None)
+            with open(args.launch_flops, "w") as f:
+                json.dump(tally, f, indent=1)
         loss_d, adv, emo = eng.loss_d_out[0].item(), eng.adv.item(), eng.emo.item()
 
     cpu = None
@@ -391,7 +462,7 @@ def main():
                                    "(1 critic update incl. gradient penalty + 1 generator update)",
                        "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
                        "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2)},
-            "roofline": roof, "cpu_baseline": cpu, "secondary": sched,
+            "event_timing": event_timing, "roofline": roof, "cpu_baseline": cpu, "secondary": sched,
             "losses": {"loss_d": round(loss_d, 5), "g_adv": round(adv, 5), "g_emo": round(emo, 5)},
         }
         print(json.dumps(line), flush=True)

@@ -191,6 +191,13 @@ def gan_case(name, B, T, C, n_steps=3, mode="warm_start", ed_mode="notes", seed=
         z = O.closed_form((B, cfg["NOISE_DIM"]), 11.0, 1.0)
         gen, _ = G(z, latent, E(numeric))
     out["end.generated"] = gen.numpy().copy()
+    # the same generation with the generator's BatchNorm on BATCH statistics (G.train(), E_num still eval): unlike the
+    # eval-mode output it does not depend on the pre-BatchNorm conv biases / running means, whose values are Adam-amplified
+    # rounding noise in the reference itself -- the tight pin of a free-running end state
+    G.train()
+    with torch.no_grad():
+        gen_tr, _ = G(z, latent, E(numeric))
+    out["end.generated_train"] = gen_tr.numpy().copy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "loss_d", [out[f"s{i}.loss_d"] for i in range(n_steps)], "emo", out[f"s{n_steps-1}.emo"])
 

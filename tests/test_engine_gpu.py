@@ -274,7 +274,8 @@ def test_workspaces_outlive_the_graphs_that_captured_them(engine_mod):
         engines.append(e)
     real, numeric, latent, emot = O.synthetic_batch(32, 512, 4, cfg["LATENT_DIM"], 6, 1)
     e_graph, e_eager = engines
-    key = lambda: (str(e_graph.dev), "wgrad_multi", e_graph.stream.cuda_stream)  # noqa: E731
+    def scratch():          # the engine stream's 'wgrad_multi' scratch buffer (ops.workspace keys by device, tag, stream)
+        return [b for (d, tag, st), b in ops._ws_cache.items() if tag == "wgrad_multi" and st == e_graph.stream.cuda_stream][0]
     with torch.cuda.stream(e_graph.stream):
         for e in engines:
             e.set_batch(real.cuda(), numeric.cuda(), latent.cuda(), emot.cuda())
@@ -286,9 +287,9 @@ def test_workspaces_outlive_the_graphs_that_captured_them(engine_mod):
                     e.run("g_step_rng", graph)
             if it == 2:                                   # critic graph exists, the generator step has not run yet
                 assert not isinstance(e_graph._graphs["d_step_rng"], str) and "g_step_rng" not in e_graph._graphs
-                ptrs.append(ops._ws_cache[key()].data_ptr())
+                ptrs.append(scratch().data_ptr())
         torch.cuda.synchronize()
-    now = ops._ws_cache[key()].data_ptr()
+    now = scratch().data_ptr()
     if now != ptrs[0]:                                    # the buffer grew: the captured one must still be alive
         assert any(b.data_ptr() == ptrs[0] for b in ops._ws_retired)
     assert torch.equal(e_graph.D.data, e_eager.D.data) and torch.equal(e_graph.GE.data, e_eager.GE.data)

@@ -17,15 +17,16 @@ def rel_err(a, b):
 
 
 def assert_update_matches(P, old, P_ref, grads_ref, lr, skip=()):
-    """First Adam step at full size, element by element: the update is -lr * g / (|g| + eps), so wherever the gradient
-    is well-conditioned (|g| >= 1e-3 max|g| of its tensor: no cancellation to rounding noise) ours and the oracle's must
-    agree to a fraction of lr; the rest only has to stay within the +-lr any Adam step makes."""
+    """First Adam step at full size, element by element.  The update is -lr * g / (|g| + eps): wherever the gradient
+    is well-conditioned ours and the oracle's must agree to a fraction of lr; elsewhere it only has to stay within
+    the +-lr any Adam step makes.  Well-conditioned = |g| at least 30x the per-element error the gradient checks above
+    tolerate (3e-3 relative L2, i.e. 3e-3 * rms(g) per element): smaller elements may legitimately differ in sign."""
     for k, v_ref in P_ref.items():
         if k in skip:
             continue
         upd, upd_ref = P[k].detach().cpu() - old[k], v_ref - old[k]
         gref = grads_ref[k]
-        mask = gref.abs() >= 1e-3 * gref.abs().max()
+        mask = gref.abs() >= 30 * 3e-3 * gref.pow(2).mean().sqrt()
         assert float(mask.float().mean()) > 0.2, (k, float(mask.float().mean()))
         worst = float((upd - upd_ref)[mask].abs().max())
         assert worst <= 1e-3 * lr, (k, worst / lr)

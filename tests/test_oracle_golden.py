@@ -109,6 +109,11 @@ def test_gan_steps_match_reference(name):
     # (see PRE_BN_BIAS) is only 10 %/step absorbed by the running mean, so the trained
     # eval output carries that noise times invstd; train-mode outputs (s0.fake_d) do not.
     np.testing.assert_allclose(gen.numpy(), g["end.generated"], rtol=1e-3, atol=5e-5)
+    # ... which is why the fixtures also hold the same generation on BATCH statistics: invariant to those biases
+    with torch.no_grad():
+        BG = type(S.BG)((k, v.clone()) for k, v in S.BG.items())
+        gen_tr, _ = O.generator_fwd(S.PG, BG, z, latent, emb, cfg["INTEGRATION_MODE"], cfg["MAX_NOTES"], train=True)
+    np.testing.assert_allclose(gen_tr.numpy(), g["end.generated_train"], rtol=2e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["layers_c4_t16_b2", "layers_c128_t32_b2"])
