@@ -156,6 +156,15 @@ int mg_bn_train_fwd(const float* z, float* a, long R, int C,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* save_mean, float* save_invstd, int act,
                     void* work, size_t work_bytes, mg_stream_t stream);
+/* The same over `groups` independent batches of R rows each, stacked along the rows of z / a (the generator forward of
+ * the critic step and of the generator step run as one 2B-row pass: src/gan/train_gan.py:186-189 and :216-219 use the
+ * same generator weights): batch statistics per group (save_mean / save_invstd: (groups, C)), running statistics
+ * updated group after group -- what consecutive forward calls do.  `work`: mg_bn_groups_workspace_bytes(C, groups). */
+size_t mg_bn_groups_workspace_bytes(int C, int groups);
+int mg_bn_train_fwd_groups(const float* z, float* a, long R, int C, int groups, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps,
+                           float* save_mean, float* save_invstd, int act,
+                           void* work, size_t work_bytes, mg_stream_t stream);
 /* backward: da (grad wrt a), a (forward output: the ReLU / LeakyReLU mask, tanh'), z.  Produces dz, dgamma, dbeta.
  * beta: only read for act = MG_ACT_GELU, whose derivative is taken at the BN output (recomputed from z); else may be NULL. */
 int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, long R, int C,
@@ -262,6 +271,10 @@ int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, fl
 int mg_rng_fill_tick(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
                      float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
                      double* adam_state, float beta1, float beta2, mg_stream_t stream);
+/* One draw serving TWO updates (critic and generator step fused into one graph): both Adam states are advanced. */
+int mg_rng_fill_tick2(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
+                      float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
+                      double* adam_state, double* adam_state2, float beta1, float beta2, mg_stream_t stream);
 
 /* ---- fused flat Adam / AdamW (torch.optim.Adam defaults; src/gan/train_gan.py:136-145,
  *      src/ae/train_ae.py:79).  state: double[4] = {step, beta1^step, beta2^step, unused},
@@ -270,7 +283,8 @@ int mg_rng_fill_tick(float* normal, long n_normal, float* uniform, long n_unifor
 int mg_adam_flat(float* p, const float* g, float* m, float* v, long n,
                  float lr, float beta1, float beta2, float eps, float weight_decay,
                  double* state, float grad_scale, const float* gs_dev, mg_stream_t stream);
-/* The update alone, for a state that mg_rng_fill_tick has already advanced; advances *rng_step (see there). */
+/* The update alone, for a state that mg_rng_fill_tick has already advanced; advances *rng_step (see there) unless
+ * rng_step is NULL (the second of the two updates behind one mg_rng_fill_tick2 draw). */
 int mg_adam_flat_ticked(float* p, const float* g, float* m, float* v, long n,
                         float lr, float beta1, float beta2, float eps, float weight_decay,
                         const double* state, float grad_scale, const float* gs_dev, uint64_t* rng_step,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "mg_colsum": (i32, [vp, i64, i32, vp, vp, vp, sz, vp]),
     "mg_bn_workspace_bytes": (sz, [i32]),
     "mg_bn_train_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp, sz, vp]),
+    "mg_bn_groups_workspace_bytes": (sz, [i32, i32]),
+    "mg_bn_train_fwd_groups": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp, sz, vp]),
     "mg_bn_train_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
     "mg_bn_eval_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, i32, vp]),
     "mg_bn_fold": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, vp]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "mg_act_bwd": (i32, [vp, vp, i32, vp, vp, i64, vp]),
     "mg_rng_fill": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp]),
     "mg_rng_fill_tick": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, f32, f32, vp]),
+    "mg_rng_fill_tick2": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, vp, f32, f32, vp]),
     "mg_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
     "mg_adam_flat_ticked": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp, vp]),
     "mg_grad_norm_workspace_bytes": (sz, [i64]),

@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                              int want_sq, const float* __restrict__ gamma = nullptr,
                                                              const float* __restrict__ beta = nullptr) {
     __shared__ double sh[2][16][65];
+    // blockIdx.z = row group (BatchNorm over several independent batches in one launch): R rows each, contiguous
+    x += (long)blockIdx.z * R * C;
+    part += (long)blockIdx.z * (RED_SPLITS + 1) * 2 * C;
     const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c0 = blockIdx.x * 64 + 4 * cq;
     const long r0 = (long)blockIdx.y * rows_per;
@@ -158,33 +161,41 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restr
     if (sumsq) sumsq[c] = (float)s2;
 }
 
+// groups > 1: independent batches of R rows each (the generator forward of the critic step and of the generator step as
+// one 2B-row pass): statistics per group, running statistics updated group after group -- exactly what two consecutive
+// forward passes do.
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nsplit, int C,
                                                              long R, float momentum, float eps, float* running_mean,
                                                              float* running_var, float* save_mean,
-                                                             float* save_invstd) {
-    double s1, s2;
-    int c;
-    if (!reduce_partials(part, nsplit, C, true, s1, s2, c)) return;
-    const double mean = s1 / (double)R;
-    double var = s2 / (double)R - mean * mean;
-    if (var < 0.0) var = 0.0;
-    save_mean[c] = (float)mean;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+                                                             float* save_invstd, int groups) {
+    for (int g = 0; g < groups; ++g) {
+        double s1, s2;
+        int c;
+        const bool mine = reduce_partials(part + (long)g * (RED_SPLITS + 1) * 2 * C, nsplit, C, true, s1, s2, c);
+        __syncthreads();
+        if (!mine) continue;
+        const double mean = s1 / (double)R;
+        double var = s2 / (double)R - mean * mean;
+        if (var < 0.0) var = 0.0;
+        save_mean[(long)g * C + c] = (float)mean;
+        save_invstd[(long)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
     }
 }
 
 __global__ void bn_apply_kernel(const float* __restrict__ z, float* __restrict__ a, long n, int C,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ mean, const float* __restrict__ invstd, int act) {
+                                const float* __restrict__ mean, const float* __restrict__ invstd, int act, long group_n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
+    const long gc = (i / group_n) * C + c;           // statistics of the element's row group
     // fp64 per-element math (free at HBM-bound rates; matches ATen's CPU accumulate type)
-    const double v = ((double)z[i] - (double)mean[c]) * (double)invstd[c] * (double)gamma[c] + (double)beta[c];
+    const double v = ((double)z[i] - (double)mean[gc]) * (double)invstd[gc] * (double)gamma[c] + (double)beta[c];
     a[i] = mg_act(act, (float)v);
 }
 
@@ -662,14 +673,18 @@ struct RngJobs { RngJob j[4]; int njobs; };
 // matching adam_apply advances step_ctr (which only this kernel reads): each of the two launches ticks the counter
 // the OTHER one reads, so neither needs a launch of its own.
 __global__ void rng_fill_kernel(const RngJobs jobs, unsigned long long seed, unsigned long long* step_ctr,
-                                double* tick_state, double beta1, double beta2) {
+                                double* tick_state, double* tick_state2, double beta1, double beta2) {
     const unsigned long long step = step_ctr[0];
     const int jid = blockIdx.y;
-    if (tick_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        if (tick_state[0] == 0.0) { tick_state[1] = 1.0; tick_state[2] = 1.0; }
-        tick_state[0] += 1.0;
-        tick_state[1] *= beta1;
-        tick_state[2] *= beta2;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        double* const st[2] = {tick_state, tick_state2};      // one draw may serve two updates (the fused critic + generator step)
+        for (int k = 0; k < 2; ++k)
+            if (st[k]) {
+                if (st[k][0] == 0.0) { st[k][1] = 1.0; st[k][2] = 1.0; }
+                st[k][0] += 1.0;
+                st[k][1] *= beta1;
+                st[k][2] *= beta2;
+            }
     }
     if (jid < jobs.njobs) {
         const RngJob jb = jobs.j[jid];
@@ -846,22 +861,32 @@ int mg_colsum(const float* x, long R, int C, float* sum, float* sumsq, void* wor
     return MG_OK;
 }
 
-int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
-                    float* save_invstd, int act, void* work, size_t work_bytes, mg_stream_t stream) {
-    MG_CHECK_ARG(z && a && gamma && beta && save_mean && save_invstd && R > 0 && C > 0, "mg_bn_train_fwd: bad args");
+size_t mg_bn_groups_workspace_bytes(int C, int groups) { return (size_t)(groups < 1 ? 1 : groups) * mg_colsum_workspace_bytes(C); }
+
+int mg_bn_train_fwd_groups(const float* z, float* a, long R, int C, int groups, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                           float* save_invstd, int act, void* work, size_t work_bytes, mg_stream_t stream) {
+    MG_CHECK_ARG(z && a && gamma && beta && save_mean && save_invstd && R > 0 && C > 0 && groups >= 1 && groups <= 64,
+                 "mg_bn_train_fwd: bad args");
     MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "mg_bn_train_fwd: running stats must come in pairs");
-    if (!work || work_bytes < mg_bn_workspace_bytes(C)) { mg_set_error("mg_bn_train_fwd: workspace too small"); return MG_EWORK; }
+    if (!work || work_bytes < mg_bn_groups_workspace_bytes(C, groups)) { mg_set_error("mg_bn_train_fwd: workspace too small"); return MG_EWORK; }
     const RedPlan pl = red_plan(R);
-    dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
+    dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit, (unsigned)groups);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, z, nullptr, nullptr, nullptr, nullptr, 0, R, C,
                        pl.rows_per, (double*)work, 1);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C, FIN_CH)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, R,
-                       momentum, eps, running_mean, running_var, save_mean, save_invstd);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, z, a, R * C, C, gamma, beta, save_mean,
-                       save_invstd, act);
+                       momentum, eps, running_mean, running_var, save_mean, save_invstd, groups);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C * groups)), dim3(256), 0, ST, z, a, R * C * groups, C, gamma, beta,
+                       save_mean, save_invstd, act, R * C);
     MG_CHECK_LAUNCH("bn_train_fwd");
     return MG_OK;
+}
+
+int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                    float* save_invstd, int act, void* work, size_t work_bytes, mg_stream_t stream) {
+    return mg_bn_train_fwd_groups(z, a, R, C, 1, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                                  save_invstd, act, work, work_bytes, stream);
 }
 
 int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, long R, int C, const float* gamma,
@@ -1091,7 +1116,7 @@ int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, 
 
 static int rng_fill_impl(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
                          float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
-                         double* tick_state, float beta1, float beta2, mg_stream_t stream) {
+                         double* tick_state, double* tick_state2, float beta1, float beta2, mg_stream_t stream) {
     MG_CHECK_ARG(step_counter != nullptr, "mg_rng_fill: null step counter");
     MG_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mg_rng_fill: bad dropout probability");
     RngJobs jobs{};
@@ -1109,7 +1134,7 @@ static int rng_fill_impl(float* normal, long n_normal, float* uniform, long n_un
     unsigned gx = (unsigned)mg_cdiv(mg_cdiv(mx, 4), 256);
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(rng_fill_kernel, dim3(gx, n), dim3(256), 0, ST, jobs, (unsigned long long)seed,
-                       (unsigned long long*)step_counter, tick_state, (double)beta1, (double)beta2);
+                       (unsigned long long*)step_counter, tick_state, tick_state2, (double)beta1, (double)beta2);
     if (!tick_state)
         hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, ST, (unsigned long long*)step_counter);
     MG_CHECK_LAUNCH("rng_fill");
@@ -1120,7 +1145,7 @@ int mg_rng_fill(float* normal, long n_normal, float* uniform, long n_uniform, fl
                            float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
                            mg_stream_t stream) {
     return rng_fill_impl(normal, n_normal, uniform, n_uniform, mask0, n_mask0, mask1, n_mask1, p_drop, seed,
-                         step_counter, nullptr, 0.f, 0.f, stream);
+                         step_counter, nullptr, nullptr, 0.f, 0.f, stream);
 }
 
 int mg_rng_fill_tick(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0,
@@ -1129,7 +1154,16 @@ int mg_rng_fill_tick(float* normal, long n_normal, float* uniform, long n_unifor
                                 mg_stream_t stream) {
     MG_CHECK_ARG(adam_state, "mg_rng_fill_tick: null adam_state");
     return rng_fill_impl(normal, n_normal, uniform, n_uniform, mask0, n_mask0, mask1, n_mask1, p_drop, seed,
-                         step_counter, adam_state, beta1, beta2, stream);
+                         step_counter, adam_state, nullptr, beta1, beta2, stream);
+}
+
+int mg_rng_fill_tick2(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0,
+                      long n_mask0, float* mask1, long n_mask1, float p_drop, uint64_t seed,
+                      uint64_t* step_counter, double* adam_state, double* adam_state2, float beta1, float beta2,
+                      mg_stream_t stream) {
+    MG_CHECK_ARG(adam_state && adam_state2 && adam_state != adam_state2, "mg_rng_fill_tick2: two distinct adam states");
+    return rng_fill_impl(normal, n_normal, uniform, n_uniform, mask0, n_mask0, mask1, n_mask1, p_drop, seed,
+                         step_counter, adam_state, adam_state2, beta1, beta2, stream);
 }
 
 int mg_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
@@ -1146,7 +1180,8 @@ int mg_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr,
 int mg_adam_flat_ticked(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, const double* state, float grad_scale, const float* gs_dev,
                         uint64_t* rng_step, mg_stream_t stream) {
-    MG_CHECK_ARG(p && g && m && v && state && rng_step && n > 0, "mg_adam_flat_ticked: bad args");
+    /* rng_step may be NULL: of the two updates one fused draw serves (mg_rng_fill_tick2) only one advances the counter */
+    MG_CHECK_ARG(p && g && m && v && state && n > 0, "mg_adam_flat_ticked: bad args");
     hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, state, grad_scale, gs_dev, (unsigned long long*)rng_step);
     MG_CHECK_LAUNCH("adam_flat_ticked");

@@ -127,8 +127,9 @@ class DataParallel:
         ones on RCCL's stream beside the engine's."""
         e = self.engine
         if not self.active:
-            e.run("d_step_rng", use_graph)                  # draw + D forward/backward + Adam: one graph
-            if g_step:
+            # one graph per batch: the critic step alone, or critic + generator step with ONE 2B-row generator pass
+            e.run("dg_step_rng" if g_step and hasattr(e, "dg_step_rng") else "d_step_rng", use_graph)
+            if g_step and not hasattr(e, "dg_step_rng"):
                 e.run("g_step_rng", use_graph)
             return
         e.run("d_backward_rng", use_graph)          # Philox draw (noise, alpha, dropout masks) + D fwd/bwd

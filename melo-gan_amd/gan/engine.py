@@ -204,30 +204,47 @@ class GanEngine:
         self.ed_wt = [torch.empty(ci, co, k, device=d) for (ci, co, k) in self.ed_chans]
 
         # ---- static inputs ----
+        # Everything the E_num / generator forward touches has 2B rows: rows [0, B) belong to the critic step's pass
+        # (no_grad, fake batch), rows [B, 2B) to the generator step's.  Both passes use the same weights (the generator is
+        # updated only after the second one), so the production step runs them as ONE 2B-row pass with per-half dropout
+        # masks, noise and BatchNorm statistics (dg_step_rng); the split forms run one half at a time.  Unsuffixed
+        # attribute names are the generator-step half -- what the backward pass reads; `*_d` the critic-step half.
         z = lambda *s: torch.zeros(*s, device=d)  # noqa: E731
-        self.numeric, self.latent = z(B, self.num_in), z(B, self.latent_dim)
+        B2 = 2 * B
+
+        def halves(name, *shape):
+            buf = z(B2, *shape)
+            setattr(self, name + "_2", buf)
+            setattr(self, name + "_d", buf[:B])
+            setattr(self, name, buf[B:])
+
+        halves("numeric", self.num_in)            # the batch's numeric features, staged into both halves
+        self.latent = z(B, self.latent_dim)
         self.emot_idx = torch.zeros(B, dtype=torch.int64, device=d)
-        self.noise, self.alpha = z(B, self.noise_dim), z(B)
-        self.dmask = [z(B, h) for h in self.enc_hidden]         # keep-mask * 1/(1-p)
+        halves("noise", self.noise_dim)
+        self.alpha = z(B)
+        self.dmask_2 = [z(B2, h) for h in self.enc_hidden]         # keep-mask * 1/(1-p)
+        self.dmask_d, self.dmask = [m[:B] for m in self.dmask_2], [m[B:] for m in self.dmask_2]
 
         # ---- E_num / G activations ----
         h1, h2 = self.enc_hidden
-        self.e_x0, self.e_xhat = z(B, self.num_in), z(B, self.num_in)
-        self.e_z1, self.e_h1, self.e_z2, self.e_h2, self.emb = z(B, h1), z(B, h1), z(B, h2), z(B, h2), z(B, self.E)
-        self.gin, self.a_n0, self.lat = z(B, self.in_dim), z(B, 512), z(B, self.latent_dim)
-        self.a_p0, self.a_p2 = z(B, 512), z(B, 256 * self.red)
-        self.y0 = z(B, self.red, 256)
-        self.z_d0, self.a_d0 = z(B, 2 * self.red, 128), z(B, 2 * self.red, 128)
-        self.z_d3, self.a_d3 = z(B, 4 * self.red, 64), z(B, 4 * self.red, 64)
-        self.bn_mean = [z(128), z(64)]
-        self.bn_invstd = [z(128), z(64)]
+        for nm, shape in (("e_x0", (self.num_in,)), ("e_xhat", (self.num_in,)), ("e_z1", (h1,)), ("e_h1", (h1,)),
+                          ("e_z2", (h2,)), ("e_h2", (h2,)), ("emb", (self.E,)), ("gin", (self.in_dim,)), ("a_n0", (512,)),
+                          ("lat", (self.latent_dim,)), ("a_p0", (512,)), ("a_p2", (256 * self.red,)),
+                          ("y0", (self.red, 256)), ("z_d0", (2 * self.red, 128)), ("a_d0", (2 * self.red, 128)),
+                          ("z_d3", (4 * self.red, 64)), ("a_d3", (4 * self.red, 64))):
+            halves(nm, *shape)
+        self.bn_mean_2, self.bn_invstd_2 = [z(2, 128), z(2, 64)], [z(2, 128), z(2, 64)]       # per half
+        self.bn_mean, self.bn_invstd = [t[1] for t in self.bn_mean_2], [t[1] for t in self.bn_invstd_2]
         self.L3 = 8 * self.red
 
-        # ---- critic activations for 3B rows: [real | fake | x_hat] ----
+        # ---- critic activations for 3B rows: [x_hat | real | fake] ----
+        # X0 holds 4B rolls [x_hat | real | fake (critic step) | fake (generator step)]: the critic step reads rows
+        # [0, 3B) as one batch, the 2B-row generator pass writes rows [2B, 4B), the generator step reads [3B, 4B).
         c1 = lambda t: (t - 1) // 2 + 1  # noqa: E731
         self.T1, self.T2, self.T3 = c1(T), c1(c1(T)), c1(c1(c1(T)))
         Bd = 3 * B
-        self.X0 = z(Bd, T, C)
+        self.X0 = z(4 * B, T, C)
         self.A1, self.A2, self.A3 = z(Bd, self.T1, 64), z(Bd, self.T2, 128), z(Bd, self.T3, 256)
         self.H, self.Fh, self.s = z(Bd, 256), z(Bd, 256), z(Bd)
         self.dU, self.dH = z(Bd, 256), z(Bd, 256)
@@ -236,12 +253,13 @@ class GanEngine:
         self.TAN0, self.TAN1, self.TAN2 = z(B, T, C), z(B, self.T1, 64), z(B, self.T2, 128)
         self.TZ3, self.ghb, self.gfb = z(B, self.T3, 256), z(B, 256), z(B, 256)
         self.norms, self.gp = z(B), z(1)
-        self.ds_d = torch.cat([torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B), torch.ones(B)]).to(d)
+        self.ds_d = torch.cat([torch.ones(B), torch.full((B,), -1.0 / B), torch.full((B,), 1.0 / B)]).to(d)
         self.ds_g = torch.full((B,), -1.0 / B, device=d)
         self.loss_d_out, self.adv, self.emo = z(3), z(1), z(1)
 
         # ---- G-step extras ----
-        self.notes = z(B, T, C)                   # generator output (G-step)
+        self.real, self.fake_d = self.X0[B:2 * B], self.X0[2 * B:3 * B]
+        self.notes = self.X0[3 * B:]              # generator output (G-step)
         self.dnotes = z(B, T, C)
         self.dn_dense = z(B, self.L3, C) if self.L3 != T else None
         self.demb = z(B, self.E)
@@ -345,7 +363,8 @@ class GanEngine:
         """Stage one batch into the engine's input buffers.  Device sources go through ONE mg_stage_rows launch; with
         `idx` (int64 device tensor of B rows) the sources are whole resident arrays and the batch is gathered from
         them (real_idx=None: `real` alone is already a gathered batch).  Host sources take torch's copies."""
-        srcs = [(real, self.X0, idx if real_idx == "same" else real_idx), (numeric, self.numeric, idx)]
+        srcs = [(real, self.real, idx if real_idx == "same" else real_idx), (numeric, self.numeric_d, idx),
+                (numeric, self.numeric, idx)]
         if latent is not None and self.latent_dim > 0:
             srcs.append((latent, self.latent, idx))
         srcs.append((emot_idx, self.emot_idx, idx))
@@ -355,19 +374,23 @@ class GanEngine:
             return
         if idx is not None:
             raise ValueError("set_batch: gathering by idx needs contiguous device sources of the engine's dtypes")
-        self.X0[:self.B].copy_(real, non_blocking=True)
+        self.real.copy_(real, non_blocking=True)
+        self.numeric_d.copy_(numeric, non_blocking=True)
         self.numeric.copy_(numeric, non_blocking=True)
         if latent is not None:
             self.latent.copy_(latent, non_blocking=True)
         self.emot_idx.copy_(emot_idx, non_blocking=True)
 
-    def set_randoms(self, noise: Tensor, drop_masks: Optional[Sequence[Tensor]], alpha: Optional[Tensor] = None):
-        """Injected randomness.  drop_masks are {0,1} keep-masks (None => eval mode, no dropout)."""
-        self.noise.copy_(noise, non_blocking=True)
+    def set_randoms(self, noise: Tensor, drop_masks: Optional[Sequence[Tensor]], alpha: Optional[Tensor] = None,
+                    half: Optional[str] = None):
+        """Injected randomness of one sub-step.  drop_masks are {0,1} keep-masks (None => eval mode, no dropout).
+        half: 'd' = the critic step's pass (default when alpha is given), 'g' = the generator step's."""
+        half = half or ("d" if alpha is not None else "g")
+        (self.noise_d if half == "d" else self.noise).copy_(noise, non_blocking=True)
         if alpha is not None:
             self.alpha.copy_(alpha.reshape(-1), non_blocking=True)
         if drop_masks is not None:
-            for dst, m in zip(self.dmask, drop_masks):
+            for dst, m in zip(self.dmask_d if half == "d" else self.dmask, drop_masks):
                 dst.copy_(m.to(torch.float32) * (1.0 / (1.0 - P_DROP)), non_blocking=True)
 
     def draw_randoms(self, with_alpha: bool):
@@ -379,9 +402,17 @@ class GanEngine:
         # the two sub-steps draw from different Philox keys: under data parallelism the G-step's draw is issued before
         # the critic update has advanced the step counter (DataParallel.step)
         key = self.rng_seed if with_alpha else (self.rng_seed + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        ops.rng_fill(self.noise, self.alpha if with_alpha else None, self.dmask[0], self.dmask[1], P_DROP,
+        noise, masks = (self.noise_d, self.dmask_d) if with_alpha else (self.noise, self.dmask)
+        ops.rng_fill(noise, self.alpha if with_alpha else None, masks[0], masks[1], P_DROP,
                      key, self.rng_step, tick_state=fp.state, betas=self.betas)
         fp.ticked = True
+
+    def draw_randoms_both(self):
+        """The fused step's draw: noise and dropout masks of BOTH halves plus alpha in one launch, which advances both
+        optimisers' Adam states; the critic update advances the Philox counter."""
+        ops.rng_fill(self.noise_2, self.alpha, self.dmask_2[0], self.dmask_2[1], P_DROP, self.rng_seed, self.rng_step,
+                     tick_state=self.D.state, betas=self.betas, tick_state2=self.GE.state)
+        self.D.ticked, self.GE.ticked = True, "nobump"
 
     def seed(self, seed: int):
         self.rng_seed = int(seed)
@@ -396,49 +427,71 @@ class GanEngine:
     def _ep(self, k):
         return self.GE.p["E." + k]
 
-    def _e_fwd(self, train: bool):
-        """FeatureEncoder.forward (src/gan/feature_encoder.py:43-45)."""
-        P = self._ep
-        ops.layernorm_fwd(self.numeric, self.e_x0, self.e_xhat, P("net.0.weight"), P("net.0.bias"))
-        m1, m2 = (self.dmask if train else (None, None))
-        ops.linear_fwd(self.e_x0, P("net.1.weight"), self.e_h1, bias=P("net.1.bias"), zout=self.e_z1, act=ACT_GELU, emul=m1)
-        ops.linear_fwd(self.e_h1, P("net.4.weight"), self.e_h2, bias=P("net.4.bias"), zout=self.e_z2, act=ACT_GELU, emul=m2)
-        ops.linear_fwd(self.e_h2, P("net.7.weight"), self.emb, bias=P("net.7.bias"))
+    def _rows(self, which: str):
+        """Row range of the 2B-row buffers: 'd' = critic-step half, 'g' = generator-step half, 'both'."""
+        B = self.B
+        return {"d": (0, B), "g": (B, 2 * B), "both": (0, 2 * B)}[which]
 
-    def _g_fwd(self, out: Tensor, train: bool):
-        """Generator.forward (src/gan/models.py:108-130, :66-83) into `out` (B, T, C)."""
+    def _e_fwd(self, train: bool, which: str = "g"):
+        """FeatureEncoder.forward (src/gan/feature_encoder.py:43-45) on the rows of `which`."""
+        P = self._ep
+        r0, r1 = self._rows(which)
+        v = lambda name: getattr(self, name + "_2")[r0:r1]  # noqa: E731
+        ops.layernorm_fwd(v("numeric"), v("e_x0"), v("e_xhat"), P("net.0.weight"), P("net.0.bias"))
+        m1, m2 = ((self.dmask_2[0][r0:r1], self.dmask_2[1][r0:r1]) if train else (None, None))
+        ops.linear_fwd(v("e_x0"), P("net.1.weight"), v("e_h1"), bias=P("net.1.bias"), zout=v("e_z1"), act=ACT_GELU, emul=m1)
+        ops.linear_fwd(v("e_h1"), P("net.4.weight"), v("e_h2"), bias=P("net.4.bias"), zout=v("e_z2"), act=ACT_GELU, emul=m2)
+        ops.linear_fwd(v("e_h2"), P("net.7.weight"), v("emb"), bias=P("net.7.bias"))
+
+    def _g_fwd(self, out: Tensor, train: bool, which: str = "g"):
+        """Generator.forward (src/gan/models.py:108-130, :66-83) on the rows of `which` into `out` (rows, T, C)."""
         P = self._gp
+        r0, r1 = self._rows(which)
+        n = r1 - r0
+        v = lambda name: getattr(self, name + "_2")[r0:r1]  # noqa: E731
         # gin = [noise | embedding (| latent)]: the column blocks filled by one launch
         nd, E = self.noise_dim, self.E
-        blocks = [(self.noise, self.gin[:, :nd], None), (self.emb, self.gin[:, nd:nd + E], None)]
+        gin = v("gin")
+        blocks = [(v("noise"), gin[:, :nd], None), (v("emb"), gin[:, nd:nd + E], None)]
         if self.mode == "conditioning":
-            blocks.append((self.latent, self.gin[:, nd + E:nd + E + self.latent_dim], None))
-        ops.stage_rows(blocks, self.B)
-        ops.linear_fwd(self.gin, P("noise_to_latent.net.0.weight"), self.a_n0, bias=P("noise_to_latent.net.0.bias"), act=ACT_RELU)
-        ops.linear_fwd(self.a_n0, P("noise_to_latent.net.2.weight"), self.lat, bias=P("noise_to_latent.net.2.bias"))
-        ops.linear_fwd(self.lat, P("decoder.pre.0.weight"), self.a_p0, bias=P("decoder.pre.0.bias"), act=ACT_RELU)
-        ops.linear_fwd(self.a_p0, P("decoder.pre.2.weight"), self.a_p2, bias=P("decoder.pre.2.bias"), act=ACT_RELU)
-        ops.transpose_bcl_blc(self.a_p2.view(self.B, 256, self.red), self.y0)
-        ops.convT1d_fwd(self.y0, P("decoder.deconv.0.weight"), self.z_d0, bias=P("decoder.deconv.0.bias"))
-        self._bn(self.z_d0, self.a_d0, "decoder.deconv.1", 0, train)
-        ops.convT1d_fwd(self.a_d0, P("decoder.deconv.3.weight"), self.z_d3, bias=P("decoder.deconv.3.bias"))
-        self._bn(self.z_d3, self.a_d3, "decoder.deconv.4", 1, train)
-        ops.convT1d_fwd(self.a_d3, P("decoder.deconv.6.weight"), out, bias=P("decoder.deconv.6.bias"))
+            for h in range(n // self.B):          # the batch's latent, once per half
+                blocks.append((self.latent, gin[h * self.B:(h + 1) * self.B, nd + E:nd + E + self.latent_dim], None))
+        if n == self.B:
+            ops.stage_rows(blocks, n)
+        else:
+            ops.stage_rows(blocks[:2], n)
+            if len(blocks) > 2:
+                ops.stage_rows(blocks[2:], self.B)
+        ops.linear_fwd(gin, P("noise_to_latent.net.0.weight"), v("a_n0"), bias=P("noise_to_latent.net.0.bias"), act=ACT_RELU)
+        ops.linear_fwd(v("a_n0"), P("noise_to_latent.net.2.weight"), v("lat"), bias=P("noise_to_latent.net.2.bias"))
+        ops.linear_fwd(v("lat"), P("decoder.pre.0.weight"), v("a_p0"), bias=P("decoder.pre.0.bias"), act=ACT_RELU)
+        ops.linear_fwd(v("a_p0"), P("decoder.pre.2.weight"), v("a_p2"), bias=P("decoder.pre.2.bias"), act=ACT_RELU)
+        ops.transpose_bcl_blc(v("a_p2").view(n, 256, self.red), v("y0"))
+        ops.convT1d_fwd(v("y0"), P("decoder.deconv.0.weight"), v("z_d0"), bias=P("decoder.deconv.0.bias"))
+        self._bn(v("z_d0"), v("a_d0"), "decoder.deconv.1", 0, train, which)
+        ops.convT1d_fwd(v("a_d0"), P("decoder.deconv.3.weight"), v("z_d3"), bias=P("decoder.deconv.3.bias"))
+        self._bn(v("z_d3"), v("a_d3"), "decoder.deconv.4", 1, train, which)
+        ops.convT1d_fwd(v("a_d3"), P("decoder.deconv.6.weight"), out, bias=P("decoder.deconv.6.bias"))
         if train:
-            self.num_batches_tracked += 1
+            self.num_batches_tracked += n // self.B
 
-    def _bn(self, z, a, name, i, train):
+    def _bn(self, z, a, name, i, train, which="g"):
         P = self._gp
         if train:
+            groups = 2 if which == "both" else 1
+            g0 = 0 if which in ("d", "both") else 1
+            mean = self.bn_mean_2[i] if groups == 2 else self.bn_mean_2[i][g0]
+            invstd = self.bn_invstd_2[i] if groups == 2 else self.bn_invstd_2[i][g0]
             ops.bn_train_fwd(z, a, P(name + ".weight"), P(name + ".bias"), self.Gbuf[name + ".running_mean"],
-                             self.Gbuf[name + ".running_var"], self.bn_mean[i], self.bn_invstd[i], ACT_RELU, BN_MOM, BN_EPS)
+                             self.Gbuf[name + ".running_var"], mean, invstd, ACT_RELU, BN_MOM, BN_EPS, groups=groups)
         else:
             ops.bn_eval_fwd(z, a, P(name + ".weight"), P(name + ".bias"), self.Gbuf[name + ".running_mean"],
                             self.Gbuf[name + ".running_var"], ACT_RELU, BN_EPS)
 
-    def _d_fwd(self, x: Tensor, nb: int, head: bool = True):
-        """Discriminator.forward (src/gan/models.py:158-169) on the first nb rows of the critic buffers.  head=False
-        leaves the scoring head to _d_bwd_input(with_head=True), which runs it in the same launch as its gradient."""
+    def _d_fwd(self, x: Tensor, nb: int, emb: Tensor, head: bool = True):
+        """Discriminator.forward (src/gan/models.py:158-169) on the first nb rows of the critic buffers; `emb` (B rows)
+        is the numeric embedding of row r % B.  head=False leaves the scoring head to _d_bwd_input(with_head=True),
+        which runs it in the same launch as its gradient."""
         P = self.D.p
         ops.conv1d_fwd(x, P["conv.0.weight"], self.A1[:nb], 2, bias=P["conv.0.bias"], act=ACT_LRELU)
         ops.conv1d_fwd(self.A1[:nb], P["conv.2.weight"], self.A2[:nb], 2, bias=P["conv.2.bias"], act=ACT_LRELU)
@@ -446,13 +499,13 @@ class GanEngine:
         ops.meanT_fwd(self.A3[:nb], self.H[:nb])
         ops.linear_fwd(self.H[:nb], P["fc.1.weight"], self.Fh[:nb], bias=P["fc.1.bias"], act=ACT_LRELU)
         if head:
-            ops.dhead_fwd(self.Fh[:nb], self.emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb])
+            ops.dhead_fwd(self.Fh[:nb], emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb])
 
-    def _d_bwd_input(self, ds: Tensor, nb: int, demb: Optional[Tensor], with_head: bool = False):
+    def _d_bwd_input(self, ds: Tensor, nb: int, emb: Tensor, demb: Optional[Tensor], with_head: bool = False):
         """Back-propagate ds through the critic down to dZ1 (grad wrt conv.0's pre-activation)."""
         P = self.D.p
         if with_head:
-            ops.dhead_fwd_bwd(ds, self.Fh[:nb], self.emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb],
+            ops.dhead_fwd_bwd(ds, self.Fh[:nb], emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb],
                               self.dU[:nb], demb, nb_emb=nb if demb is not None else 0)
         else:
             ops.dhead_bwd(ds, self.Fh[:nb], P["real_fake.weight"].view(-1), self.dU[:nb], demb,
@@ -536,38 +589,42 @@ class GanEngine:
     # -------------------------------------------------------------------------------------
     # D-step  (src/gan/train_gan.py:183-205)
     # -------------------------------------------------------------------------------------
-    def d_backward(self):
+    def d_backward(self, forward: bool = True):
+        """forward=False: the fake batch (rows [2B, 3B) of X0) and the embedding of the critic-step half already exist
+        (dg_forward ran the 2B-row generator pass)."""
         B = self.B
         P, G = self.D.p, self.D.g
-        # no_grad: embedding (dropout ON) and fake batch (BN train mode: running stats move)
-        self._e_fwd(train=True)
-        self._g_fwd(self.X0[B:2 * B], train=True)
-        ops.gp_interp(self.X0[:B], self.X0[B:2 * B], self.alpha, self.X0[2 * B:])
-        self._d_fwd(self.X0, 3 * B, head=False)
-        # one backward for [real | fake | x_hat] with ds = [-1/B | +1/B | 1]
-        self._d_bwd_input(self.ds_d, 3 * B, None, with_head=True)
-        ops.conv1d_dgrad(self.dZ1[2 * B:], P["conv.0.weight"], self.gx, 2)
+        if forward:
+            # no_grad: embedding (dropout ON) and fake batch (BN train mode: running stats move)
+            self._e_fwd(True, "d")
+            self._g_fwd(self.fake_d, True, "d")
+        ops.gp_interp(self.real, self.fake_d, self.alpha, self.X0[:B])
+        self._d_fwd(self.X0[:3 * B], 3 * B, self.emb_d, head=False)
+        # one backward for [x_hat | real | fake] with ds = [1 | -1/B | +1/B]
+        self._d_bwd_input(self.ds_d, 3 * B, self.emb_d, None, with_head=True)
+        ops.conv1d_dgrad(self.dZ1[:B], P["conv.0.weight"], self.gx, 2)
         ops.gp_penalty(self.gx, self.TAN0, self.norms, None, self.lambda_gp)      # mean((norm-1)^2): in wgan_d_loss
         # Weight gradients are [real,fake] activations x Wasserstein dZ + tangent activations x penalty dZ; each
-        # becomes launchable as soon as its tangent exists, so they run on side streams next to the tangent pass
-        # (d(lambda*gp)/d(grad_xhat) pushed forward through the masked linear critic).
-        ops.conv1d_fwd(self.TAN0, P["conv.0.weight"], self.TAN1, 2, gref=self.A1[2 * B:], gact=ACT_LRELU)
-        ops.conv1d_fwd(self.TAN1, P["conv.2.weight"], self.TAN2, 2, gref=self.A2[2 * B:], gact=ACT_LRELU)
-        ops.conv1d_fwd(self.TAN2, P["conv.4.weight"], self.TZ3, 2, gref=self.A3[2 * B:], gact=ACT_LRELU)
+        # becomes launchable as soon as its tangent exists (d(lambda*gp)/d(grad_xhat) pushed forward through the
+        # masked linear critic).
+        ops.conv1d_fwd(self.TAN0, P["conv.0.weight"], self.TAN1, 2, gref=self.A1[:B], gact=ACT_LRELU)
+        ops.conv1d_fwd(self.TAN1, P["conv.2.weight"], self.TAN2, 2, gref=self.A2[:B], gact=ACT_LRELU)
+        ops.conv1d_fwd(self.TAN2, P["conv.4.weight"], self.TZ3, 2, gref=self.A3[:B], gact=ACT_LRELU)
         # the three convolutions' weight gradients go out as ONE launch (+ one slab reduction) once their tangents
         # exist (ops.wgrad_multi): three launches of ~256 workgroups each plus three reductions before
         ops.wgrad_multi([
-            ops.conv1d_wgrad(self.X0[:2 * B], self.dZ1[:2 * B], G["conv.0.weight"], 2, self.TAN0, self.dZ1[2 * B:],
+            ops.conv1d_wgrad(self.X0[B:3 * B], self.dZ1[B:], G["conv.0.weight"], 2, self.TAN0, self.dZ1[:B],
                              db=G["conv.0.bias"], defer=True),
-            ops.conv1d_wgrad(self.A1[:2 * B], self.dZ2[:2 * B], G["conv.2.weight"], 2, self.TAN1, self.dZ2[2 * B:],
+            ops.conv1d_wgrad(self.A1[B:], self.dZ2[B:], G["conv.2.weight"], 2, self.TAN1, self.dZ2[:B],
                              db=G["conv.2.bias"], defer=True),
-            ops.conv1d_wgrad(self.A2[:2 * B], self.dZ3[:2 * B], G["conv.4.weight"], 2, self.TAN2, self.dZ3[2 * B:],
+            ops.conv1d_wgrad(self.A2[B:], self.dZ3[B:], G["conv.4.weight"], 2, self.TAN2, self.dZ3[:B],
                              db=G["conv.4.bias"], defer=True)])
         ops.meanT_fwd(self.TZ3, self.ghb)
-        ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[2 * B:], gact=ACT_LRELU)
-        ops.linear_wgrad(self.H[:2 * B], self.dU[:2 * B], G["fc.1.weight"], self.ghb, self.dU[2 * B:], db=G["fc.1.bias"])
-        ops.dhead_wgrad(self.ds_d, self.Fh, self.emb, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"], 2 * B, B)
-        ops.wgan_d_loss(self.s, self.gp, self.lambda_gp, self.loss_d_out, B, norms=self.norms)
+        ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[:B], gact=ACT_LRELU)
+        ops.linear_wgrad(self.H[B:], self.dU[B:], G["fc.1.weight"], self.ghb, self.dU[:B], db=G["fc.1.bias"])
+        ops.dhead_wgrad(self.ds_d[B:], self.Fh[B:], self.emb_d, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"],
+                        2 * B, B)
+        ops.wgan_d_loss(self.s[B:], self.gp, self.lambda_gp, self.loss_d_out, B, norms=self.norms)
         self._join()
 
     def d_backward_rng(self):
@@ -589,6 +646,33 @@ class GanEngine:
         self.g_backward_rng()
         self.g_update()
 
+    # ---- the fused step: one critic update + one generator update with ONE 2B-row generator pass ----
+    def dg_forward(self):
+        """E_num + generator forward of the critic step AND of the generator step as one pass over 2B rows: both use the
+        same weights (train_gan.py:186-189 and :216-219 -- the generator is not updated in between), each half has its own
+        noise, dropout masks and BatchNorm batch statistics, and the running statistics move twice, critic-step half first."""
+        if not self._ed_folded:
+            self.fold_ed()
+        self._e_fwd(True, "both")
+        self._g_fwd(self.X0[2 * self.B:], True, "both")
+
+    def dg_step_rng(self):
+        """Draw + critic step + generator step as ONE capturable sequence (single-GPU production path whenever a
+        generator update follows the critic update on the same batch)."""
+        self.draw_randoms_both()
+        self.dg_forward()
+        self.d_backward(forward=False)
+        self.d_update()
+        self.g_backward_a2()
+        self.g_backward_b()
+        self.g_update()
+
+    def dg_forward_d_backward_rng(self):
+        """Data parallelism: everything of the fused step in front of the critic's gradient all-reduce."""
+        self.draw_randoms_both()
+        self.dg_forward()
+        self.d_backward(forward=False)
+
     def g_backward_a_rng(self):
         self.draw_randoms(with_alpha=False)
         self.g_backward_a()
@@ -607,7 +691,7 @@ class GanEngine:
     def _adam(self, fp, lr):
         """The optimiser step; after draw_randoms() the Adam state is already advanced (fp.ticked)."""
         ops.adam_flat(fp.data, fp.grad, fp.m, fp.v, fp.state, lr, *self.betas, grad_scale=1.0 / self.world_size,
-                      ticked_rng_step=self.rng_step if fp.ticked else None)
+                      ticked_rng_step=self.rng_step if fp.ticked is True else None, ticked=bool(fp.ticked))
         fp.ticked = False
 
     def d_update(self):
@@ -625,8 +709,8 @@ class GanEngine:
         the critic's gradient all-reduce is in flight (DataParallel.step)."""
         if not self._ed_folded:
             self.fold_ed()
-        self._e_fwd(train=True)
-        self._g_fwd(self.notes, train=True)
+        self._e_fwd(True, "g")
+        self._g_fwd(self.notes, True, "g")
 
     def g_forward_rng(self):
         self.draw_randoms(with_alpha=False)
@@ -644,8 +728,8 @@ class GanEngine:
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         # the critic branch (forward + input gradient) runs beside the emotion-discriminator branch
         with self._branch(0, critic=True):
-            self._d_fwd(self.notes, B, head=False)
-            self._d_bwd_input(self.ds_g, B, self.demb, with_head=True)
+            self._d_fwd(self.notes, B, self.emb, head=False)
+            self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True)
             ops.neg_mean(self.s[:B], self.adv)
         self._ed_fwd(self.notes)
         ops.softmax_ce(self.logits, self.emot_idx, self.emo, self.dlogits, self.lambda_emo)
@@ -741,20 +825,23 @@ class GanEngine:
     # graph capture / replay
     # -------------------------------------------------------------------------------------
     def run(self, name: str, use_graph: bool = True):
-        """Run one of d_backward / d_update / g_backward / g_update, replaying its hipGraph when
-        captured (the first call runs eagerly, which also warms every workspace)."""
+        """Run one of the sub-step methods (d_backward, d_update, g_step_rng, dg_step_rng, ...), replaying its hipGraph
+        when captured (the first call runs eagerly, which also warms every workspace)."""
         fn = getattr(self, name)
         if not use_graph:
             return fn()
-        # An update graph exists in two forms (Adam state advanced by the preceding draw, or by itself); a replayed
-        # graph does not run the Python that tracks which one applies, so it is tracked here by sub-step name.
+        # An update graph exists in several forms (Adam state advanced by the preceding draw -- with or without the
+        # Philox counter to advance -- or by itself); a replayed graph does not run the Python that tracks which one
+        # applies, so it is tracked here by sub-step name.
         fp_upd = {"d_update": self.D, "g_update": self.GE}.get(name)
-        key = name + ("#ticked" if fp_upd is not None and fp_upd.ticked else "")
+        key = name + (f"#{fp_upd.ticked}" if fp_upd is not None and fp_upd.ticked else "")
         try:
             return self._run_graph(key, fn)
         finally:
-            if name.endswith("_step_rng"):                      # draw and update both inside: nothing left pending
+            if name.endswith("_step_rng"):                      # draw and update(s) both inside: nothing left pending
                 self.D.ticked = self.GE.ticked = False
+            elif name == "dg_forward_d_backward_rng":           # the fused draw: both updates are still to come
+                self.D.ticked, self.GE.ticked = True, "nobump"
             elif name.endswith("_rng"):
                 (self.D if name.startswith("d_") else self.GE).ticked = True
             if fp_upd is not None:
@@ -767,23 +854,29 @@ class GanEngine:
             self._graphs[name] = "warm"
             return
         if st == "warm":
-            if torch.cuda.current_stream() == torch.cuda.default_stream():
-                raise RuntimeError("GanEngine.run: capture needs a non-default stream (use `with torch.cuda.stream(eng.stream)`)")
-            nbt = self.num_batches_tracked
-            torch.cuda.synchronize()
-            g = ops.Graph()
-            g.begin()
-            try:
-                fn()
-            finally:
-                g.end()
-            self.num_batches_tracked = nbt
-            self._graphs[name] = g
-            st = g
-        st.launch()
-        if name in ("d_backward", "g_backward", "d_backward_rng", "g_backward_rng", "g_backward_a", "g_backward_a_rng",
-                    "g_forward", "g_forward_rng", "d_step_rng", "g_step_rng"):
-            self.num_batches_tracked += 1
+            if getattr(self, "capture_locked", False):
+                raise RuntimeError(f"GanEngine.run({name}): graph capture after DataParallel.prepare() -- every sub-step of "
+                                   "a data-parallel run must be captured before the first collective is issued")
+            st = self._capture(name, fn)
+        st[0].launch()
+        self.num_batches_tracked += st[1]
+
+    def _capture(self, name: str, fn):
+        """Capture fn's launches from the current stream into a hipGraph; returns (graph, BatchNorm forward passes it
+        contains -- num_batches_tracked is host state a replay does not touch)."""
+        if torch.cuda.current_stream() == torch.cuda.default_stream():
+            raise RuntimeError("GanEngine.run: capture needs a non-default stream (use `with torch.cuda.stream(eng.stream)`)")
+        nbt = self.num_batches_tracked
+        torch.cuda.synchronize()
+        g = ops.Graph()
+        g.begin()
+        try:
+            fn()
+        finally:
+            g.end()
+        delta, self.num_batches_tracked = self.num_batches_tracked - nbt, nbt
+        self._graphs[name] = (g, delta)
+        return self._graphs[name]
 
     # -------------------------------------------------------------------------------------
     # inference (app.py:92-119: E_num -> G in eval mode)
@@ -793,7 +886,7 @@ class GanEngine:
         self.numeric.copy_(numeric)
         if latent is not None:
             self.latent.copy_(latent)
-        self._e_fwd(train=False)
-        self._g_fwd(self.notes, train=False)
+        self._e_fwd(False, "g")
+        self._g_fwd(self.notes, False, "g")
         return self.notes
 

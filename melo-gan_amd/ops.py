@@ -410,21 +410,27 @@ def colsum(x: Tensor, out: Tensor, sumsq: Optional[Tensor] = None):
 
 
 def bn_train_fwd(z, a, gamma, beta, running_mean, running_var, save_mean, save_invstd, act=ACT_RELU,
-                 momentum=0.1, eps=1e-5):
+                 momentum=0.1, eps=1e-5, groups=1):
+    """groups > 1: z / a stack `groups` independent batches along dim 0 (statistics per group, save_* of shape
+    (groups, C), running statistics updated group after group)."""
     _chk(z, "z")
     _chk(a, "a", z.shape)
     Cc = z.shape[-1]
     R = z.numel() // Cc
-    for nm, v in (("gamma", gamma), ("beta", beta), ("save_mean", save_mean), ("save_invstd", save_invstd)):
+    if groups < 1 or z.shape[0] % groups:
+        raise ValueError(f"bn_train_fwd: {z.shape[0]} batch rows do not split into {groups} groups")
+    for nm, v in (("gamma", gamma), ("beta", beta)):
         _chk(v, nm, (Cc,))
+    for nm, v in (("save_mean", save_mean), ("save_invstd", save_invstd)):
+        _chk(v, nm, (Cc,) if groups == 1 else (groups, Cc))
     if running_mean is not None:
         _chk(running_mean, "running_mean", (Cc,))
         _chk(running_var, "running_var", (Cc,))
     lib = L.load()
-    work = workspace(lib.mg_bn_workspace_bytes(Cc), z.device, "bn")
-    L.check(lib.mg_bn_train_fwd(_p(z), _p(a), R, Cc, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                momentum, eps, _p(save_mean), _p(save_invstd), act, _p(work), work.numel(),
-                                _stream()), "mg_bn_train_fwd")
+    work = workspace(lib.mg_bn_groups_workspace_bytes(Cc, groups), z.device, "bn")
+    L.check(lib.mg_bn_train_fwd_groups(_p(z), _p(a), R // groups, Cc, groups, _p(gamma), _p(beta), _p(running_mean),
+                                       _p(running_var), momentum, eps, _p(save_mean), _p(save_invstd), act, _p(work),
+                                       work.numel(), _stream()), "mg_bn_train_fwd")
     return a
 
 
@@ -714,7 +720,7 @@ def act_bwd(dy, dx, gref=None, gact=ACT_NONE, emul=None):
     L.check(L.load().mg_act_bwd(_p(dy), _p(gref), gact, _p(emul), _p(dx), n, _stream()), "mg_act_bwd")
 
 
-def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_state=None, betas=None):
+def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_state=None, betas=None, tick_state2=None):
     """normal ~ N(0,1), uniform ~ U(0,1), mask* = keep-mask/(1-p_drop); any of them may be None.  Plain: draw, then
     advance step_counter (two launches).  With tick_state (an optimiser's Adam state) and betas: ONE launch that
     draws and advances that Adam state instead; adam_flat(..., ticked_rng_step=step_counter) later advances the counter."""
@@ -723,6 +729,13 @@ def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_sta
             _chk(t, "rng tensor")
     _chk(step_counter, "step_counter", (1,), torch.int64)
     n = lambda t: 0 if t is None else t.numel()  # noqa: E731
+    if tick_state2 is not None:          # one draw in front of two updates: both Adam states advance here
+        _chk(tick_state, "tick_state", (4,), torch.float64)
+        _chk(tick_state2, "tick_state2", (4,), torch.float64)
+        L.check(L.load().mg_rng_fill_tick2(_p(normal), n(normal), _p(uniform), n(uniform), _p(mask0), n(mask0), _p(mask1),
+                                           n(mask1), p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(step_counter), _p(tick_state),
+                                           _p(tick_state2), betas[0], betas[1], _stream()), "mg_rng_fill_tick2")
+        return
     if tick_state is not None:
         _chk(tick_state, "tick_state", (4,), torch.float64)
         L.check(L.load().mg_rng_fill_tick(_p(normal), n(normal), _p(uniform), n(uniform), _p(mask0), n(mask0), _p(mask1),
@@ -734,17 +747,19 @@ def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_sta
 
 
 def adam_flat(p, g, m, v, state, lr, beta1, beta2, eps=1e-8, weight_decay=0.0, grad_scale=1.0, gs_dev=None,
-              ticked_rng_step=None):
+              ticked_rng_step=None, ticked=False):
     """Fused flat Adam/AdamW.  ticked_rng_step: `state` was already advanced by rng_fill(tick_state=state); apply the
-    update only and advance that Philox step counter (one launch instead of two)."""
+    update only and advance that Philox step counter (one launch instead of two).  ticked=True without a counter: the
+    state was advanced by the draw, and another update advances the counter (rng_fill(tick_state2=...))."""
     n = p.numel()
     for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _chk(t, nm)
         if t.numel() != n:
             raise ValueError("adam_flat: size mismatch")
     _chk(state, "state", (4,), torch.float64)
-    if ticked_rng_step is not None:
-        _chk(ticked_rng_step, "ticked_rng_step", (1,), torch.int64)
+    if ticked_rng_step is not None or ticked:
+        if ticked_rng_step is not None:
+            _chk(ticked_rng_step, "ticked_rng_step", (1,), torch.int64)
         L.check(L.load().mg_adam_flat_ticked(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, _p(state),
                                              grad_scale, _p(gs_dev), _p(ticked_rng_step), _stream()), "mg_adam_flat_ticked")
         return

@@ -78,9 +78,9 @@ def test_batch_stage_fills_the_engine_like_set_batch():
                 t.fill_(float("nan"))
             eng.emot_idx.fill_(-1)
             batch.stage(eng)
-            got = [eng.X0[:B].clone(), eng.numeric.clone(), eng.latent.clone(), eng.emot_idx.clone()]
+            got = [eng.real.clone(), eng.numeric.clone(), eng.latent.clone(), eng.emot_idx.clone()]
             eng.set_batch(notes.cpu(), numeric.cpu(), latent.cpu(), emot.cpu())          # host sources: torch copies
-            want = [eng.X0[:B], eng.numeric, eng.latent, eng.emot_idx]
+            want = [eng.real, eng.numeric, eng.latent, eng.emot_idx]
             assert all(torch.equal(a, b) for a, b in zip(got, want))
             assert torch.equal(got[0], notes) and torch.equal(got[3], emot)
             seen += 1

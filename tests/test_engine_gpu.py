@@ -88,10 +88,10 @@ def test_steps_match_oracle_and_golden(engine_mod, name):
         assert abs(ld[0].item() - float(g[f"s{it}.loss_d"])) <= 1e-4 * abs(float(g[f"s{it}.loss_d"]))
         assert abs(eng.gp.item() - float(g[f"s{it}.gp"])) <= 1e-4
         B = eng.B
-        np.testing.assert_allclose(eng.s[:B].cpu().numpy(), g[f"s{it}.d_real"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(eng.s[B:2 * B].cpu().numpy(), g[f"s{it}.d_real"], rtol=1e-4, atol=2e-6)
         # d_fake inherits the generator's BatchNorm conditioning (see the fake_d comment below)
-        np.testing.assert_allclose(eng.s[B:2 * B].cpu().numpy(), g[f"s{it}.d_fake"], rtol=5e-3, atol=2e-5)
-        ok, errs = grad_ok(eng.s[B:2 * B], rd["d_fake"], rd64["d_fake"], slack=8.0, floor=2e-6)
+        np.testing.assert_allclose(eng.s[2 * B:].cpu().numpy(), g[f"s{it}.d_fake"], rtol=5e-3, atol=2e-5)
+        ok, errs = grad_ok(eng.s[2 * B:], rd["d_fake"], rd64["d_fake"], slack=8.0, floor=2e-6)
         assert ok, ("d_fake", errs)
         # (slices of the weight gradients: tolerance relative to the tensor's mean |g| -- individual small
         #  elements are differences of large cancelling terms)
@@ -99,8 +99,8 @@ def test_steps_match_oracle_and_golden(engine_mod, name):
             # train-mode BatchNorm over a handful of rows amplifies fp32 rounding (invstd up to 316 per
             # layer): against the reference's fp32 output allow 2e-3 / 2e-5, and require that we are no
             # further from the fp64 truth than a few times the reference's own fp32 arithmetic is.
-            np.testing.assert_allclose(eng.X0[B:2 * B].cpu().numpy(), g["s0.fake_d"], rtol=2e-3, atol=2e-5)
-            ok, errs = grad_ok(eng.X0[B:2 * B], rd["fake"], rd64["fake"], slack=8.0, floor=2e-6)
+            np.testing.assert_allclose(eng.fake_d.cpu().numpy(), g["s0.fake_d"], rtol=2e-3, atol=2e-5)
+            ok, errs = grad_ok(eng.fake_d, rd["fake"], rd64["fake"], slack=8.0, floor=2e-6)
             assert ok, ("fake_d", errs)
             np.testing.assert_allclose(eng.D.g["conv.0.weight"][:4].cpu().numpy(), g["s0.dgrad_conv0_w"], rtol=1e-3,
                                        atol=5e-2 * float(g["s0.dgrad.conv.0.weight"][2]) / eng.D.p["conv.0.weight"].numel())
@@ -245,7 +245,9 @@ def test_production_flow_is_bitwise_reproducible_and_matches_the_dp_flow(engine_
                         e.run("d_update")
             torch.cuda.synchronize()
         assert torch.isfinite(e.D.data).all() and torch.isfinite(e.GE.data).all()
-        assert int(e.rng_step.item()) == 6 + 3 and float(e.D.state[0].item()) == 6.0 and float(e.GE.state[0].item()) == 3.0
+        # Philox draws: one per batch in the fused flow (dg_step_rng draws both halves at once), one per sub-step otherwise
+        assert int(e.rng_step.item()) == (6 if flow == "step" else 6 + 3)
+        assert float(e.D.state[0].item()) == 6.0 and float(e.GE.state[0].item()) == 3.0
         return e.D.data.clone(), e.GE.data.clone(), e.loss_d_out.clone()
 
     for flow in ("step", "dp_order"):
@@ -293,3 +295,47 @@ def test_workspaces_outlive_the_graphs_that_captured_them(engine_mod):
     if now != ptrs[0]:                                    # the buffer grew: the captured one must still be alive
         assert any(b.data_ptr() == ptrs[0] for b in ops._ws_retired)
     assert torch.equal(e_graph.D.data, e_eager.D.data) and torch.equal(e_graph.GE.data, e_eager.GE.data)
+
+
+def test_fused_step_matches_the_two_separate_steps(engine_mod):
+    """dg_forward runs the critic step's and the generator step's E_num + generator forward as ONE 2B-row pass (same
+    weights, per-half noise / dropout masks / BatchNorm statistics, running statistics updated twice).  With the same
+    injected randoms it must reproduce the two separate passes: every gradient, both losses, both fake batches, the
+    running statistics -- to fp32 summation-order accuracy (the 2B-row launches tile and split their reductions
+    differently), and the replayed one-graph step must equal its eager self bit for bit."""
+    g = load("gan_c128_t64_b4")
+    S, e1, cfg, _ = make(engine_mod, g)
+    _, e2, _, _ = make(engine_mod, g)
+    R = O.step_randoms(e1.B, cfg["NOISE_DIM"], seed=31)
+    for e in (e1, e2):
+        e.set_randoms(R["noise_d"].cuda(), [m.cuda() for m in R["dm_d"]], R["alpha"].cuda())
+        e.set_randoms(R["noise_g"].cuda(), [m.cuda() for m in R["dm_g"]])
+    e1.d_backward(); gd1 = e1.D.grad.clone(); e1.d_update()
+    e1.g_backward(); gg1 = e1.GE.grad.clone(); e1.g_update()
+    e2.dg_forward()
+    e2.d_backward(forward=False); gd2 = e2.D.grad.clone(); e2.d_update()
+    e2.g_backward_a2(); e2.g_backward_b(); gg2 = e2.GE.grad.clone(); e2.g_update()
+    torch.cuda.synchronize()
+    assert e1.num_batches_tracked == e2.num_batches_tracked == 2
+    for a, b, what in ((e1.fake_d, e2.fake_d, "fake_d"), (e1.notes, e2.notes, "fake_g"), (e1.emb_d, e2.emb_d, "emb_d"),
+                       (e1.loss_d_out, e2.loss_d_out, "loss_d"), (e1.adv, e2.adv, "adv"), (e1.emo, e2.emo, "emo")):
+        assert rel_err(b, a) < 2e-5, (what, rel_err(b, a))
+    for k in e1.Gbuf:
+        assert rel_err(e2.Gbuf[k], e1.Gbuf[k]) < 1e-5, k
+    assert rel_err(gd2, gd1) < 1e-4, rel_err(gd2, gd1)
+    for k, (o, n) in e1.GE.offsets.items():
+        if k in NOISE_PARAMS_G:
+            continue
+        assert rel_err(gg2[o:o + n], gg1[o:o + n]) < 2e-3, (k, rel_err(gg2[o:o + n], gg1[o:o + n]))     # BatchNorm-conditioned
+    # the production form: draw + both steps as one replayed graph == the same sequence launched eagerly
+    _, e3, _, batch = make(engine_mod, g)
+    _, e4, _, _ = make(engine_mod, g)
+    with torch.cuda.stream(e4.stream):
+        for e, graph in ((e3, False), (e4, True)):
+            e.seed(9)
+            for _ in range(4):
+                e.run("dg_step_rng", graph)
+        torch.cuda.synchronize()
+    assert torch.equal(e3.D.data, e4.D.data) and torch.equal(e3.GE.data, e4.GE.data) and torch.equal(e3.notes, e4.notes)
+    assert e3.num_batches_tracked == e4.num_batches_tracked == 8 and int(e4.rng_step.item()) == 4
+    assert float(e4.D.state[0].item()) == 4.0 and float(e4.GE.state[0].item()) == 4.0

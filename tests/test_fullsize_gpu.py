@@ -59,7 +59,7 @@ def test_full_size_step_matches_oracle(setup):
     rd = O.d_step(S, real, latent, numeric, R["noise_d"], R["alpha"], R["dm_d"])
     assert abs(eng.loss_d_out[0].item() - rd["loss_d"].item()) <= 2e-4 * abs(rd["loss_d"].item())
     assert abs(eng.gp.item() - rd["gp"].item()) <= 2e-4 * abs(rd["gp"].item())
-    torch.testing.assert_close(eng.X0[B:2 * B].cpu(), rd["fake"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(eng.fake_d.cpu(), rd["fake"], rtol=1e-3, atol=1e-5)
     for k, g in rd["grads"].items():
         got = eng.D.g[k]
         if k == "real_fake.bias":

@@ -60,12 +60,12 @@ def test_free_running_trajectory_matches_reference(name):
         B = eng.B
         eng.set_randoms(cu("noise_d"), [cu("dm_d0").float(), cu("dm_d1").float()], cu("alpha"))
         eng.d_backward()
-        d_real = eng.s[:B].cpu().numpy().copy()
+        d_real = eng.s[B:2 * B].cpu().numpy().copy()          # critic rows: [x_hat | real | fake]
         # The critic's output OFFSET is a free, noise-driven degree of freedom of the model: the head's bias and the
         # embedding half of its weight receive +1/B and -1/B contributions that cancel exactly, so their gradient is
         # rounding noise and Adam moves them by +-lr_d per critic update (in the reference too).  loss_d is blind to it
         # (same offset on real and fake); the raw scores and adv = -mean(D(fake)) carry it:
-        offset_noise = it * eng.lr_d * (1.0 + float(eng.emb.abs().sum(dim=1).max().item()))
+        offset_noise = it * eng.lr_d * (1.0 + float(eng.emb_d.abs().sum(dim=1).max().item()))
         np.testing.assert_allclose(d_real, g[f"s{it}.d_real"], rtol=TRAJ_RTOL, atol=2e-5 + offset_noise)
         eng.d_update()
         offset_noise += eng.lr_d * (1.0 + float(eng.emb.abs().sum(dim=1).max().item()))
