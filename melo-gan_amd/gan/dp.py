@@ -6,17 +6,36 @@ gradient buffers (critic 1.25 MB every batch; generator + numeric encoder 18.8 M
 steps), the 1/world factor folded into the fused Adam launch (grad_scale).  On ROCm the "nccl"
 backend is RCCL over xGMI.
 
-Three step orders (MELO_DP_MODE, default "gather"):
-  gather     decoder.pre.2.weight -- 16.8 of the generator's 18.8 MB -- is never all-reduced: its gradient is
-             d_p2^T a_p0, so the ranks all-gather those two per-sample factors (2.2 MB per rank) and each computes
-             the global batch's weight gradient itself (GanEngine.enable_p2_gather).  Per generator step: all-reduce
-             critic (1.25 MB), all-gather 2 MB + 128 KB per rank, all-reduce the remaining 2 MB.  Bytes received
-             per rank at N = 2 / 4 / 8: 4.4 / 9 / 18 MB instead of 20 / 30 / 35 MB.  No overlap with compute.
-  allreduce  one all-reduce per optimiser, no overlap.
-  overlap    the critic's all-reduce beside the generator forward and pre.2's slice beside the rest of backward.
-             Measured on one MI355X with a 1-rank RCCL group (bench.py, MELO_FORCE_DP=1): a collective left in
-             flight across a hipGraph launch costs ~85 us each -- 1.53 ms/step against 1.35 for "allreduce" and
-             1.32 without collectives -- more than the transfer it can hide, hence not the default.
+A batch's step is a fixed sequence of hipGraphs with the collectives between them.  With a generator update:
+
+    G1  dg_forward_d_backward_rng   one Philox draw, the 2B-row E_num + generator pass, the critic step's forward/backward
+    C1  all-reduce(critic gradient, 1.25 MB)
+    G2  g_ed_branch                 frozen emotion discriminator forward + input gradient: does not touch the critic
+    G3  d_update_g_critic_chain     critic Adam, critic forward/backward on the generated batch, generator data
+                                    gradients down to decoder.pre.2
+    C2  all-gather of pre.2's two gradient factors (mode overlap / gather) -- see below
+    G4  g_backward_b                deconvolution + Linear weight gradients, the rest of the backward chain
+    G5  g_p2_wgrad                  pre.2's global weight gradient from the gathered factors
+    C3  all-reduce(everything else of the generator / encoder gradient, 2 MB)
+    G6  g_update
+
+Step orders (MELO_DP_MODE, default "overlap"):
+  overlap    C1 and C2 are issued asynchronously (RCCL's own stream, ordered behind the engine's by an event) and
+             waited for where their result is needed: C1 runs beside G2 (~250 us of convolutions at cfg2), C2 beside G4
+             (~150 us), so the transfers -- and the ~45 us cross-stream hand-off an asynchronous collective costs, measured
+             in round 1 -- hide behind compute that does not depend on them.  C3 is small and synchronous.
+  gather     the same collectives, all synchronous on the engine's stream in program order (no overlap).
+  allreduce  one synchronous all-reduce per optimiser, no factor gather.
+
+Factor gather: decoder.pre.2.weight is 16.8 of the generator's 18.8 MB and its gradient is d_p2^T a_p0, so the ranks
+all-gather those two per-sample factors (2.2 MB per rank) and each computes the global batch's weight gradient itself
+(GanEngine.enable_p2_gather).  Bytes received per rank at N = 2 / 4 / 8: 4.4 / 9 / 18 MB instead of 20 / 30 / 35 MB.
+
+Graph capture and the process group's watchdog: torch's watchdog thread polls the completion event of every collective,
+and HIP refuses an event query while the stream the event was recorded on is capturing.  A synchronous collective
+records its event on the ENGINE's stream, so no capture may follow one.  prepare() therefore runs -- once, before the
+first collective -- two dry steps of each kind (collectives replaced by local copies) that warm up and capture every
+graph the step order uses, restores the training state, and locks the engine against later captures.
 
 BatchNorm semantics under sharding (decision, SURVEY hard part 4): the generator's train-mode
 BatchNorm uses the LOCAL shard's statistics (DDP-style), i.e. each rank runs exactly the
@@ -28,24 +47,26 @@ from __future__ import annotations
 
 import os
 
+MODES = ("overlap", "gather", "allreduce")
+
+
 class DataParallel:
     def __init__(self, engine, world_size: int, dist=None, group=None, force_collectives: bool = False):
-        """force_collectives: issue the collectives (and take the overlapped step order) even at world_size 1 -- a
+        """force_collectives: issue the collectives (and take the N > 1 step order) even at world_size 1 -- a
         rehearsal of the N > 1 control path on a single-GPU box."""
         self.engine, self.world, self.dist, self.group = engine, int(world_size), dist, group
         self.active = dist is not None and (self.world > 1 or force_collectives)
         self._dry = os.environ.get("MELO_DP_DRY") == "1"      # rehearsal: the N > 1 step order without the collectives
-        self.mode = os.environ.get("MELO_DP_MODE", "gather")
-        if self.mode not in ("gather", "allreduce", "overlap"):
-            raise ValueError(f"MELO_DP_MODE={self.mode}: expected gather | allreduce | overlap")
-        if self.mode == "gather" and not hasattr(engine, "enable_p2_gather"):
+        self.mode = os.environ.get("MELO_DP_MODE", "overlap")
+        if self.mode not in MODES:
+            raise ValueError(f"MELO_DP_MODE={self.mode}: expected one of {MODES}")
+        if self.mode != "allreduce" and not hasattr(engine, "enable_p2_gather"):
             self.mode = "allreduce"
-        if self.active and self.mode == "gather":
+        if self.active and self.mode != "allreduce":
             engine.enable_p2_gather(self.world)
-        if self.active and self.mode == "overlap":
-            engine.p2_in_a2 = True       # pre.2's weight gradient must exist when g_backward_a2 ends
         engine.world_size = self.world
         self._pending = []
+        self._prepared = False
 
     def _flat_state(self):
         e = self.engine
@@ -68,103 +89,60 @@ class DataParallel:
             import torch
             torch.cuda.synchronize()
 
-    def _allreduce(self, flat):
+    # ---- graph capture before the first collective ---------------------------------------------------------
+    def prepare(self, use_graph: bool = True):
+        """Warm up and capture every hipGraph of this mode's step order (with and without a generator update) by two
+        dry steps each -- the engine's first run of a sub-step is eager, the second captures -- then restore the training
+        state and forbid later captures.  Must run on the engine's stream, after set_batch() has staged finite inputs,
+        before the first step().  A no-op for engines without graphs (the CPU stand-ins of the tests) or use_graph=False."""
+        e = self.engine
+        self._prepared = True
+        if not self.active or not use_graph or not hasattr(e, "_capture"):
+            return
+        import torch
+        keep = [e.D.data, e.D.grad, e.D.m, e.D.v, e.D.state, e.GE.data, e.GE.grad, e.GE.m, e.GE.v, e.GE.state, e.rng_step]
+        keep += list(e.Gbuf.values())
+        saved = [t.clone() for t in keep]
+        nbt, ticked = e.num_batches_tracked, (e.D.ticked, e.GE.ticked)
+        dry, self._dry = self._dry, True
+        try:
+            for g_step in (True, True, False, False):
+                self._step(True, g_step)
+        finally:
+            self._dry = dry
+        torch.cuda.synchronize()
+        for t, v in zip(keep, saved):
+            t.copy_(v)
+        e.num_batches_tracked, (e.D.ticked, e.GE.ticked) = nbt, ticked
+        torch.cuda.synchronize()
+        e.capture_locked = True
+
+    # ---- collectives -----------------------------------------------------------------------------------------
+    def _allreduce(self, flat, async_op: bool = False):
         if not self.active or self._dry:
             return
-        # A synchronous collective runs ON the calling (engine) stream: no cross-stream hop (an async_op + wait pair
-        # cost ~45 us more per collective on one MI355X with a 1-rank RCCL group).  Its completion event is recorded
-        # on that stream and polled by the process group's watchdog thread, which must not coincide with a graph
-        # capture on the same stream: ops.Graph.begin() drains the device and the watchdog first.
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
-
-    def allreduce_d(self):
-        self._allreduce(self.engine.D.grad)
-
-    def allreduce_g(self):
-        self._allreduce(self.engine.GE.grad)
-
-    # ---- overlapped variant for the generator step --------------------------------------------------------
-    # decoder.pre.2.weight is 89 % of the G+E_num gradient bytes and is final ~100 us before the end of backward
-    # (SURVEY hard part 5).  start_g_big() launches its all-reduce asynchronously (RCCL runs on its own stream,
-    # ordered after the launching stream) while the caller enqueues the rest of backward; finish_g() all-reduces
-    # the two small remaining slices and waits for the big one.
-    def start_g_big(self):
-        if not self.active or self._dry:
-            return
-        off, n = self.engine.big_grad_slice()
-        self._pending.append(self.dist.all_reduce(self.engine.GE.grad[off:off + n], op=self.dist.ReduceOp.SUM,
-                                                  group=self.group, async_op=True))
-
-    def finish_g(self):
-        """All-reduces what start_g_big() left (one contiguous range: the engine places the big tensor first in the
-        flat buffer) and waits for the big slice."""
-        if not self.active:
-            return
-        off, n = self.engine.big_grad_slice()
-        g = self.engine.GE.grad
-        if off > 0:
-            self._allreduce(g[:off])
-        if off + n < g.numel():
-            self._allreduce(g[off + n:])
-        self._wait()
+        # A synchronous collective runs ON the calling (engine) stream: no cross-stream hop.  An asynchronous one runs on
+        # RCCL's stream behind an event of the calling stream; wait() makes the calling stream wait for it (no host block).
+        w = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            self._pending.append(w)
 
     def _wait(self):
         for w in self._pending:
             w.wait()
         self._pending.clear()
 
-    # ---- the critic's gradient: latency-bound 1.25 MB, hidden behind the G-step's generator forward -------------
-    def start_d(self):
-        if not self.active or self._dry:
-            return
-        self._pending.append(self.dist.all_reduce(self.engine.D.grad, op=self.dist.ReduceOp.SUM, group=self.group,
-                                                  async_op=True))
+    def allreduce_d(self, async_op: bool = False):
+        self._allreduce(self.engine.D.grad, async_op)
 
-    def step(self, use_graph: bool = True, g_step: bool = True):
-        """One training step (1 critic update, optionally 1 generator update) on the batch already set with
-        engine.set_batch().  world == 1: two graphs per sub-step.  world > 1: the step order of MELO_DP_MODE (module
-        docstring).  "gather" / "allreduce": synchronous collectives on the engine's stream; "overlap": asynchronous
-        ones on RCCL's stream beside the engine's."""
-        e = self.engine
-        if not self.active:
-            # one graph per batch: the critic step alone, or critic + generator step with ONE 2B-row generator pass
-            e.run("dg_step_rng" if g_step and hasattr(e, "dg_step_rng") else "d_step_rng", use_graph)
-            if g_step and not hasattr(e, "dg_step_rng"):
-                e.run("g_step_rng", use_graph)
-            return
-        e.run("d_backward_rng", use_graph)          # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
-        if not g_step:
-            self.allreduce_d()
-            e.run("d_update", use_graph)
-            return
-        if self.mode == "overlap":
-            self.start_d()
-            e.run("g_forward_rng", use_graph)
-            self._wait()
-            e.run("d_update", use_graph)
-            e.run("g_backward_a2", use_graph)
-            self.start_g_big()
-            e.run("g_backward_b", use_graph)
-            self.finish_g()
-            e.run("g_update", use_graph)
-            return
-        self.allreduce_d()
-        e.run("d_update", use_graph)
-        if self.mode == "allreduce":
-            e.run("g_backward_rng", use_graph)
-            self.allreduce_g()
-        else:
-            e.run("g_backward_a_rng", use_graph)    # ... down to pre.2's output gradient; no pre.2 weight gradient yet
-            self.gather_p2()
-            e.run("g_backward_p2b", use_graph)      # pre.2's global weight gradient + the rest of backward
-            self.allreduce_g_rest()
-        e.run("g_update", use_graph)
+    def allreduce_g(self):
+        self._allreduce(self.engine.GE.grad)
 
-    # ---- factor gather for decoder.pre.2.weight (mode "gather") ----------------------------------------------
-    def gather_p2(self):
+    def gather_p2(self, async_op: bool = False):
+        """All-gather of decoder.pre.2's gradient factors (d_p2: (B, 256 red), a_p0: (B, 512)) in rank order."""
         e = self.engine
         for src, dst in ((e.d_p2, e.d_p2_all), (e.a_p0, e.a_p0_all)):
-            if self._dry:
+            if not self.active or self._dry:
                 dst[:src.shape[0]].copy_(src)
             elif src.is_cuda and self.dist.get_backend(self.group) == "gloo":
                 # rehearsal of several ranks on one GPU: gloo has no all_gather for device tensors
@@ -172,7 +150,9 @@ class DataParallel:
                 self.dist.all_gather_into_tensor(host, src.cpu(), group=self.group)
                 dst.copy_(host)
             else:
-                self.dist.all_gather_into_tensor(dst, src, group=self.group)
+                w = self.dist.all_gather_into_tensor(dst, src, group=self.group, async_op=async_op)
+                if async_op:
+                    self._pending.append(w)
 
     def allreduce_g_rest(self):
         """Everything of the generator / numeric-encoder gradient except pre.2's weight and bias (first in the flat
@@ -182,3 +162,41 @@ class DataParallel:
         if off != 0:
             raise RuntimeError("gather mode expects decoder.pre.2 at offset 0 of the flat gradient")
         self._allreduce(e.GE.grad[n:])
+
+    # ---- the step --------------------------------------------------------------------------------------------
+    def step(self, use_graph: bool = True, g_step: bool = True):
+        """One training step (1 critic update, optionally 1 generator update) on the batch already set with
+        engine.set_batch().  world == 1: one graph per batch.  world > 1: the step order of MELO_DP_MODE (module
+        docstring)."""
+        e = self.engine
+        if not self.active:
+            # one graph per batch: the critic step alone, or critic + generator step with ONE 2B-row generator pass
+            e.run("dg_step_rng" if g_step else "d_step_rng", use_graph)
+            return
+        if not self._prepared:
+            self.prepare(use_graph)
+        self._step(use_graph, g_step)
+
+    def _step(self, use_graph: bool, g_step: bool):
+        e = self.engine
+        asyn = self.mode == "overlap"
+        if not g_step:
+            e.run("d_backward_rng", use_graph)        # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
+            self.allreduce_d()
+            e.run("d_update", use_graph)
+            return
+        e.run("dg_forward_d_backward_rng", use_graph)
+        self.allreduce_d(async_op=asyn)               # C1 ...
+        e.run("g_ed_branch", use_graph)               # ... beside the emotion discriminator's forward / backward
+        self._wait()
+        e.run("d_update_g_critic_chain", use_graph)
+        if self.mode == "allreduce":
+            e.run("g_backward_b", use_graph)
+            self.allreduce_g()
+        else:
+            self.gather_p2(async_op=asyn)             # C2 ...
+            e.run("g_backward_b", use_graph)          # ... beside the weight gradients and the rest of the backward chain
+            self._wait()
+            e.run("g_p2_wgrad", use_graph)
+            self.allreduce_g_rest()
+        e.run("g_update", use_graph)

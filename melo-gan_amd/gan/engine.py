@@ -24,9 +24,7 @@ the oracle's draws and production runs fill the same buffers from the device RNG
 from __future__ import annotations
 
 import math
-import os
 from collections import OrderedDict
-from contextlib import contextmanager
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -290,16 +288,12 @@ class GanEngine:
         self._graphs = {}
         # hipGraph capture is illegal on the null stream: every step runs on this side stream
         self.stream = torch.cuda.Stream(device=d)
-        # Side streams for independent branches of a step (weight gradients next to the data-gradient chain, the
-        # critic next to the emotion discriminator), captured as parallel graph branches.  MEASURED (round 1, cfg2):
-        # single-stream graphs are fastest -- 1.695 ms/step vs 1.73 (critic branch only) vs 1.82 (all branches):
-        # once the kernels themselves fill the chip, every fork/join costs more cross-queue latency than the
-        # overlap returns.  Default is therefore "none"; MELO_BRANCH=all|big|critic re-enables them.
-        self.side = [torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)]
-        self.branch_mode = os.environ.get("MELO_BRANCH", "none")
+        # (Forked side streams for independent branches of a step were implemented and measured in round 1: every
+        # fork/join cost more cross-queue latency than the overlap returned once the kernels filled the chip -- 1.70 ms
+        # single-stream vs 1.73-1.82 -- and were removed; independent launches of one kernel share a launch instead.)
         self.world_size = 1
         self.p2_world = 0          # > 0: decoder.pre.2's weight gradient comes from all-gathered factors (enable_p2_gather)
-        self.p2_in_a2 = False      # True: pre.2's weight gradient is launched by g_backward_a2 (DataParallel 'overlap' mode)
+        self.capture_locked = False   # DataParallel.prepare(): every graph is captured before the first collective
         self._ed_folded = False
 
     # -------------------------------------------------------------------------------------
@@ -566,26 +560,6 @@ class GanEngine:
                              gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1])
         ops.conv1d_dgrad(self.ed_dz[0], P["encoder.conv.0.net.0.weight"], dnotes, 1)
 
-    @contextmanager
-    def _branch(self, i: int, small: bool = False, critic: bool = False):
-        """Run the enclosed launches on side stream i, ordered after everything enqueued so far on the
-        current stream (fork).  _join() makes the current stream wait for the side streams again.
-        `small` marks branches that only hold a few microseconds of work (MELO_BRANCH=big keeps those inline,
-        MELO_BRANCH=none disables all side streams)."""
-        if self.branch_mode == "none" or (small and self.branch_mode in ("big", "critic")) or \
-                (self.branch_mode == "critic" and not critic):
-            yield
-            return
-        s = self.side[i]
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            yield
-
-    def _join(self):
-        cur = torch.cuda.current_stream()
-        for s in self.side:
-            cur.wait_stream(s)
-
     # -------------------------------------------------------------------------------------
     # D-step  (src/gan/train_gan.py:183-205)
     # -------------------------------------------------------------------------------------
@@ -625,7 +599,6 @@ class GanEngine:
         ops.dhead_wgrad(self.ds_d[B:], self.Fh[B:], self.emb_d, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"],
                         2 * B, B)
         ops.wgan_d_loss(self.s[B:], self.gp, self.lambda_gp, self.loss_d_out, B, norms=self.norms)
-        self._join()
 
     def d_backward_rng(self):
         """Production D-step front half: device RNG draw + d_backward as one capturable sequence."""
@@ -724,23 +697,28 @@ class GanEngine:
 
     def g_backward_a2(self):
         """g_backward_a without the generator forward (see g_forward)."""
-        B = self.B
-        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
-        # the critic branch (forward + input gradient) runs beside the emotion-discriminator branch
-        with self._branch(0, critic=True):
-            self._d_fwd(self.notes, B, self.emb, head=False)
-            self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True)
-            ops.neg_mean(self.s[:B], self.adv)
+        self.g_ed_branch()
+        self.g_critic_chain()
+
+    def g_ed_branch(self):
+        """The frozen emotion discriminator's forward, cross-entropy and input gradient on the generated batch: the only
+        part of the generator step that does not touch the critic -- under data parallelism it runs while the critic's
+        gradient all-reduce is in flight (DataParallel.step)."""
+        if not self._ed_folded:
+            self.fold_ed()
         self._ed_fwd(self.notes)
         ops.softmax_ce(self.logits, self.emot_idx, self.emo, self.dlogits, self.lambda_emo)
-        if self.ed_mode == "notes":
-            self._ed_bwd(self.dnotes)
-            acc = True
-        else:
-            self._ed_bwd(None)
-            acc = False
-        self._join()
-        ops.conv1d_dgrad(self.dZ1[:B], self.D.p["conv.0.weight"], self.dnotes, 2, accumulate=acc)
+        self._ed_bwd(self.dnotes if self.ed_mode == "notes" else None)
+
+    def g_critic_chain(self):
+        """Critic forward + input gradient on the generated batch (with the UPDATED critic), added to the emotion
+        branch's gradient, then the generator's data-gradient chain down to decoder.pre.2."""
+        B = self.B
+        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
+        self._d_fwd(self.notes, B, self.emb, head=False)
+        self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True)
+        ops.neg_mean(self.s[:B], self.adv)
+        ops.conv1d_dgrad(self.dZ1[:B], self.D.p["conv.0.weight"], self.dnotes, 2, accumulate=self.ed_mode == "notes")
         # ---- generator backward: the data-gradient chain down to decoder.pre.2, then pre.2's weight gradient -- 89 % of
         # the generator's gradient bytes, all-reduced while g_backward_b runs.  The deconvolutions' weight gradients
         # are not on that chain and wait in g_backward_b, where they widen the window the all-reduce hides in. ----
@@ -757,12 +735,13 @@ class GanEngine:
         ops.convT1d_dgrad(self.d_zd0, PG("decoder.deconv.0.weight"), self.d_y0)
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red), gref=self.a_p2, gact=ACT_RELU)
-        if self.p2_world:
-            pass    # data parallel, factor gather: g_backward_p2b computes weight and bias gradient from every rank's (d_p2, a_p0)
-        elif self.p2_in_a2:
-            ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"))
-        # otherwise g_backward_b launches it together with the other Linear weight gradients
-        self._join()
+        # pre.2's weight gradient: launched by g_backward_b with the other weight gradients, or -- data parallel, factor
+        # gather -- by g_p2_wgrad from every rank's (d_p2, a_p0)
+
+    def d_update_g_critic_chain(self):
+        """Data parallelism: what follows the critic's gradient all-reduce, as one graph."""
+        self.d_update()
+        self.g_critic_chain()
 
     def g_backward_b(self, extra_jobs=()):
         B = self.B
@@ -773,7 +752,7 @@ class GanEngine:
         # Linear layers, 12 launches at the launch floor before.
         dn = self.dn_dense if self.dn_dense is not None else self.dnotes
         jobs = list(extra_jobs)
-        if not self.p2_world and not self.p2_in_a2:
+        if not self.p2_world:
             jobs.append(ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
                                          defer=True))
         jobs.append(ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"), defer=True))
@@ -818,6 +797,11 @@ class GanEngine:
         self.g_backward_b([ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"],
                                             db=self.GE.g["G.decoder.pre.2.bias"], defer=True)])
 
+    def g_p2_wgrad(self):
+        """pre.2's global weight (and bias) gradient from the gathered factors alone: g_backward_b (which skips it under
+        enable_p2_gather) runs while the all-gather is in flight, this after it."""
+        ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"], db=self.GE.g["G.decoder.pre.2.bias"])
+
     def g_update(self):
         self._adam(self.GE, self.lr_g)
 
@@ -833,7 +817,7 @@ class GanEngine:
         # An update graph exists in several forms (Adam state advanced by the preceding draw -- with or without the
         # Philox counter to advance -- or by itself); a replayed graph does not run the Python that tracks which one
         # applies, so it is tracked here by sub-step name.
-        fp_upd = {"d_update": self.D, "g_update": self.GE}.get(name)
+        fp_upd = {"d_update": self.D, "g_update": self.GE, "d_update_g_critic_chain": self.D}.get(name)
         key = name + (f"#{fp_upd.ticked}" if fp_upd is not None and fp_upd.ticked else "")
         try:
             return self._run_graph(key, fn)

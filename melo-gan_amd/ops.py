@@ -803,20 +803,6 @@ def vae_loss(recon, x, mu, logvar, beta, out, drecon=None, dmu=None, dlv=None):
 # ---------------------------------------------------------------------------------------
 # hipGraph capture + events
 # ---------------------------------------------------------------------------------------
-def _quiesce_process_group():
-    """Data-parallel runs issue their collectives synchronously, i.e. ON the engine's stream (no cross-stream hop:
-    ~45 us per collective saved, measured).  torch's process-group watchdog thread polls each collective's completion
-    event until it has seen it complete, and HIP refuses an event query while the stream the event was recorded on
-    is capturing ("operation not permitted on an event last recorded in a capturing stream" -> the process aborts).
-    So before a capture: drain the device, then give the watchdog (100-ms poll period) time to retire what it holds.
-    Captures happen once per sub-step name, at start-up."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        import time
-        torch.cuda.synchronize()
-        time.sleep(0.3)
-
-
 class Graph:
     """hipGraph captured from whatever is enqueued on PyTorch's current stream between
     begin() and end()."""
@@ -825,7 +811,8 @@ class Graph:
         self.handle = C.c_void_p()
 
     def begin(self):
-        _quiesce_process_group()
+        # (Data-parallel runs capture every graph before their first collective -- DataParallel.prepare(): torch's
+        # process-group watchdog polls collective events, which HIP refuses on a capturing stream.)
         L.check(L.load().mg_graph_begin(_stream()), "mg_graph_begin")
 
     def end(self):

@@ -39,66 +39,64 @@ def _worker(rank, port, out):
     torch.set_num_threads(1)
     fd, fg = shard_grads(rank)
     params = torch.full((8,), float(rank))
-    big = (1000, 5000)                      # stand-in for decoder.pre.2.weight's slice of the flat gradient
+    NBIG = 5000                             # stand-in for decoder.pre.2's weight + bias slice of the flat gradient
     eng = types.SimpleNamespace(D=types.SimpleNamespace(grad=fd.clone(), data=params.clone()),
                                 GE=types.SimpleNamespace(grad=fg.clone(), data=params.clone() + 1), world_size=1,
-                                big_grad_slice=lambda: big)
-    os.environ["MELO_DP_MODE"] = "overlap"
-    dp = DataParallel(eng, WORLD, dist)
-    dp.broadcast_params()
-    assert eng.world_size == WORLD
-    assert torch.equal(eng.D.data, torch.zeros(8)) and torch.equal(eng.GE.data, torch.ones(8))   # rank 0's values
-    dp.allreduce_d()
-    g_plain = eng.GE.grad.clone()
-    dist.all_reduce(g_plain)
-    dp.start_g_big()                        # overlapped variant: big slice async, then the two remainders
-    dp.finish_g()
-    assert torch.equal(eng.GE.grad, g_plain)
-    if rank == 0:
-        torch.save({"d": eng.D.grad / WORLD, "g": eng.GE.grad / WORLD}, out)
-
-    # DataParallel.step(): the full step's launch order in each mode.  The fake engine writes a sub-step's gradients
-    # when that sub-step "runs" and checks what must already be reduced at each point.
-    d_sum, g_sum = fd.clone(), fg.clone()
-    dist.all_reduce(d_sum)
-    dist.all_reduce(g_sum)
-    NBIG = 5000
-    log = []
+                                p2_grad_slice=lambda: (0, NBIG))
     eng.d_p2, eng.a_p0 = torch.full((3, 4), float(rank + 1)), torch.full((3, 2), float(10 * (rank + 1)))
 
     def enable_p2_gather(world):
         eng.d_p2_all, eng.a_p0_all = torch.zeros(world * 3, 4), torch.zeros(world * 3, 2)
     eng.enable_p2_gather = enable_p2_gather
+    os.environ["MELO_DP_MODE"] = "allreduce"
+    dp = DataParallel(eng, WORLD, dist)
+    dp.broadcast_params()
+    assert eng.world_size == WORLD
+    assert torch.equal(eng.D.data, torch.zeros(8)) and torch.equal(eng.GE.data, torch.ones(8))   # rank 0's values
+    dp.allreduce_d(async_op=True)           # asynchronous form: complete after _wait()
+    dp._wait()
+    dp.allreduce_g()
+    if rank == 0:
+        torch.save({"d": eng.D.grad / WORLD, "g": eng.GE.grad / WORLD}, out)
+
+    # DataParallel.step(): the full step's launch order in each mode.  The fake engine writes a sub-step's gradients
+    # when that sub-step "runs" and checks what must already be reduced / gathered at each point.
+    d_sum, g_sum = fd.clone(), fg.clone()
+    dist.all_reduce(d_sum)
+    dist.all_reduce(g_sum)
+    log = []
 
     def run(name, use_graph):
         log.append(name)
-        if name == "d_backward_rng":
+        if name in ("d_backward_rng", "dg_forward_d_backward_rng"):
             eng.D.grad.copy_(fd)
-        elif name == "d_update":                     # the critic's all-reduce must have completed
+        elif name == "g_ed_branch":                  # may run while the critic's all-reduce is in flight: touches nothing of it
+            pass
+        elif name in ("d_update", "d_update_g_critic_chain"):     # the critic's all-reduce must have completed
             assert torch.equal(eng.D.grad, d_sum), "critic update before its all-reduce finished"
-        elif name in ("g_backward_a2", "g_backward_rng", "g_backward_a_rng"):
+        elif name == "g_backward_b":
             eng.GE.grad.copy_(fg)
-        elif name == "g_backward_p2b":               # every rank's factors, in rank order
+        elif name == "g_p2_wgrad":                   # every rank's factors, in rank order
             want = torch.cat([torch.full((3, 4), float(r + 1)) for r in range(WORLD)])
             assert torch.equal(eng.d_p2_all, want) and torch.equal(eng.a_p0_all[:, 0], 10 * want[:, 0])
             eng.GE.grad[:NBIG].copy_(g_sum[:NBIG])   # what the engine computes from them: the global-batch gradient
         elif name == "g_update":
             assert torch.equal(eng.GE.grad, g_sum), "generator update with a partially reduced gradient"
     eng.run = run
-    eng.big_grad_slice = lambda: (0, NBIG)           # the engine's layout: big tensor first, ONE remaining range
-    orders = {"overlap": ["d_backward_rng", "g_forward_rng", "d_update", "g_backward_a2", "g_backward_b", "g_update"],
-              "allreduce": ["d_backward_rng", "d_update", "g_backward_rng", "g_update"],
-              "gather": ["d_backward_rng", "d_update", "g_backward_a_rng", "g_backward_p2b", "g_update"]}
+    gather_order = ["dg_forward_d_backward_rng", "g_ed_branch", "d_update_g_critic_chain", "g_backward_b", "g_p2_wgrad", "g_update"]
+    orders = {"overlap": gather_order, "gather": gather_order,
+              "allreduce": ["dg_forward_d_backward_rng", "g_ed_branch", "d_update_g_critic_chain", "g_backward_b", "g_update"]}
     for mode, order in orders.items():
         os.environ["MELO_DP_MODE"] = mode
         dp = DataParallel(eng, WORLD, dist)
         assert dp.mode == mode
-        log.clear()
-        dp.step(True, g_step=True)
-        assert log == order, (mode, log)
-        log.clear()
-        dp.step(True, g_step=False)
-        assert log == ["d_backward_rng", "d_update"], (mode, log)
+        for _ in range(2):
+            log.clear()
+            dp.step(True, g_step=True)
+            assert log == order, (mode, log)
+            log.clear()
+            dp.step(True, g_step=False)
+            assert log == ["d_backward_rng", "d_update"], (mode, log)
     os.environ.pop("MELO_DP_MODE")
     dist.destroy_process_group()
 

@@ -96,3 +96,145 @@ def test_step_orders_run_on_a_one_rank_rccl_group(mode):
     assert line["n_gpus"] == 1 and line["value"] > 0
     for v in line["losses"].values():
         assert v == v and abs(v) < 1e6
+
+
+class _Work:
+    def wait(self):
+        return True
+
+
+class _ThreadDist:
+    """torch.distributed stand-in for two ranks living in one process as two threads (one engine and one stream each):
+    every collective is a rendezvous at a barrier with the data exchanged through a shared slot list."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, rank, world, barrier, slots):
+        self.rank, self.world, self.barrier, self.slots = rank, world, barrier, slots
+
+    def _exchange(self, t):
+        torch.cuda.current_stream().synchronize()
+        self.slots[self.rank] = t
+        self.barrier.wait()
+        return list(self.slots)
+
+    def get_backend(self, group=None):
+        return "thread"
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        ts = self._exchange(t)
+        total = ts[0].clone()
+        for x in ts[1:]:
+            total += x                      # rank order on every rank: identical bits everywhere
+        torch.cuda.current_stream().synchronize()
+        self.barrier.wait()                 # everyone has read before anyone overwrites
+        t.copy_(total)
+        return _Work()
+
+    def all_gather_into_tensor(self, dst, src, group=None, async_op=False):
+        ts = self._exchange(src)
+        n = src.shape[0]
+        for r, x in enumerate(ts):
+            dst[r * n:(r + 1) * n].copy_(x)
+        torch.cuda.current_stream().synchronize()
+        self.barrier.wait()
+        return _Work()
+
+    def broadcast(self, t, src=0, group=None, async_op=False):
+        ts = self._exchange(t)
+        if self.rank != src:
+            t.copy_(ts[src])
+        torch.cuda.current_stream().synchronize()
+        self.barrier.wait()
+        return _Work()
+
+
+@pytest.mark.parametrize("mode", ["overlap", "gather", "allreduce"])
+def test_two_engines_as_two_ranks_full_step(mode, monkeypatch):
+    """DataParallel.step for the full critic + generator step with two engines as two ranks (two threads, a barrier-based
+    stand-in for torch.distributed): graphs captured by prepare(), every collective of the mode's step order issued.
+    Afterwards both replicas hold bit-identical parameters, the reduced gradients equal the mean of the shards' own
+    gradients as the ORACLE computes them from the randoms each rank drew, and the parameters moved the way Adam moves
+    them on that averaged gradient."""
+    import threading
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.gan.dp import DataParallel
+    from melo_gan_amd.gan.engine import GanEngine
+    monkeypatch.setenv("MELO_DP_MODE", mode)
+    B, T, C, WORLD = 4, 32, 4, 2
+    cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+    barrier, slots = threading.Barrier(WORLD), [None] * WORLD
+    engs, dps, shards = [], [], []
+    for r in range(WORLD):
+        e = GanEngine(cfg, ed_cfg, "cuda", B)
+        e.load_state(S.PE, S.PG, S.BG, S.PD, S.PED, S.BED)
+        e.seed(100 + r)
+        shard = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 70 + r)
+        with torch.cuda.stream(e.stream):
+            e.set_batch(*(t.cuda() for t in shard))
+            dp = DataParallel(e, WORLD, _ThreadDist(r, WORLD, barrier, slots), force_collectives=False)
+            assert dp.active and dp.mode == mode
+            dp.prepare(True)                 # dry steps: no rendezvous, so the ranks can be prepared one after the other
+        assert e.capture_locked and int(e.rng_step.item()) == 0 and float(e.D.state[0].item()) == 0.0
+        engs.append(e); dps.append(dp); shards.append(shard)
+    for k in S.PD:
+        assert torch.equal(engs[0].D.p[k].cpu(), S.PD[k]) and torch.equal(engs[1].D.p[k].cpu(), S.PD[k])   # prepare() restored
+    errors = []
+
+    def rank_main(r):
+        try:
+            with torch.cuda.stream(engs[r].stream):
+                dps[r].broadcast_params()
+                dps[r].step(True, g_step=True)
+                torch.cuda.current_stream().synchronize()
+        except Exception as ex:                  # noqa: BLE001
+            errors.append(ex)
+            barrier.abort()
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    e0, e1 = engs
+    assert torch.equal(e0.D.data, e1.D.data) and torch.equal(e0.GE.data, e1.GE.data)          # replicas stay replicas
+    assert torch.equal(e0.D.grad, e1.D.grad)
+    assert not torch.equal(e0.noise_d, e1.noise_d)                                             # each rank its own draws
+    # emulation: the oracle on each shard with the randoms that rank drew, gradients averaged, one Adam step each
+    gd, gg = [], []
+    keep = lambda m: (m > 0).float().cpu()  # noqa: E731
+    Sd = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+    for e, (real, numeric, latent, emot) in zip(engs, shards):
+        Sr = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+        rd = O.d_step(Sr, real, latent, numeric, e.noise_d.cpu(), e.alpha.cpu(), [keep(m) for m in e.dmask_d])
+        gd.append(rd["grads"])
+    mean_d = {k: sum(g[k] for g in gd) / WORLD for k in gd[0]}
+    Sd.opt_D.step(Sd.PD, mean_d)                                   # the critic every rank holds after C1 + d_update
+    for e, (real, numeric, latent, emot) in zip(engs, shards):
+        Sr = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+        for k in Sr.PD:
+            Sr.PD[k].copy_(Sd.PD[k])
+        rg = O.g_step(Sr, latent, numeric, emot, e.noise.cpu(), [keep(m) for m in e.dmask])
+        gg.append(rg["grads"])
+    mean_g = {k: sum(g[k] for g in gg) / WORLD for k in gg[0]}
+    for k, ref in mean_d.items():
+        if k in ("real_fake.bias", "fc.1.bias"):
+            continue
+        got = e0.D.g[k].cpu() / WORLD
+        if k == "real_fake.weight":
+            got, ref = got[:, :256], ref[:, :256]
+        assert rel_err(got, ref) < 2e-3, (mode, "D", k, rel_err(got, ref))
+    for k, ref in mean_g.items():
+        if k in ("G.decoder.deconv.0.bias", "G.decoder.deconv.3.bias"):
+            continue
+        assert rel_err(e0.GE.g[k].cpu() / WORLD, ref) < 5e-3, (mode, "GE", k, rel_err(e0.GE.g[k].cpu() / WORLD, ref))
+    # first Adam step on the averaged gradient: -lr * sign(g) wherever the gradient is well-conditioned
+    for fp, mean, P0, lr in ((e0.D, mean_d, S.PD, e0.lr_d), (e0.GE, mean_g, S.PGE, e0.lr_g)):
+        for k, ref in mean.items():
+            mask = ref.abs() >= 0.1 * ref.pow(2).mean().sqrt()
+            upd = fp.p[k].cpu() - P0[k]
+            want = -lr * torch.sign(ref)
+            assert float((upd - want)[mask].abs().max()) <= 2e-2 * lr, (mode, k)

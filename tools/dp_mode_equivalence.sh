@@ -1,11 +1,11 @@
 #!/bin/bash
-# 2 ranks sharing one GPU over gloo: one epoch of the trainer CLI on synthetic rolls in MELO_DP_MODE=gather and
-# =allreduce from the same seed; prints the largest relative difference of the final generator tensors.
+# 2 ranks sharing one GPU over gloo: one epoch of the trainer CLI on synthetic rolls in MELO_DP_MODE=overlap, =gather
+# and =allreduce from the same seed; prints the largest relative difference of the final generator tensors.
 set -e
 cd "$(dirname "$0")/.."
 OUT=${1:-gpurun_out/dp_equiv}
 mkdir -p $OUT
-for m in gather allreduce; do
+for m in overlap gather allreduce; do
 python3 - <<PY
 import yaml
 c = yaml.safe_load(open("config/gan_config.yaml"))
@@ -20,16 +20,17 @@ tail -2 $OUT/$m.log
 done
 python3 - <<PY
 import torch
-a = torch.load("$OUT/gather/ck/gan_final.pth", map_location="cpu")
 b = torch.load("$OUT/allreduce/ck/gan_final.pth", map_location="cpu")
 worst = 0.0
-for part in ("G", "E_num"):
-    for k in a[part]:
-        x, y = a[part][k].double(), b[part][k].double()
-        if k in ("decoder.deconv.0.bias", "decoder.deconv.3.bias"):
-            continue        # biases in front of a train-mode BatchNorm: zero gradient, Adam-amplified rounding noise
-        if x.numel() and y.abs().max() > 0:
-            worst = max(worst, float((x - y).norm() / y.norm()))
+for mode in ("overlap", "gather"):
+    a = torch.load(f"$OUT/{mode}/ck/gan_final.pth", map_location="cpu")
+    for part in ("G", "E_num"):
+        for k in a[part]:
+            x, y = a[part][k].double(), b[part][k].double()
+            if k in ("decoder.deconv.0.bias", "decoder.deconv.3.bias"):
+                continue        # biases in front of a train-mode BatchNorm: zero gradient, Adam-amplified rounding noise
+            if x.numel() and y.abs().max() > 0:
+                worst = max(worst, float((x - y).norm() / y.norm()))
 print("largest relative difference gather vs allreduce:", worst)
 assert worst < 1e-5
 PY
