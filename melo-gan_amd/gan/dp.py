@@ -13,19 +13,23 @@ A batch's step is a fixed sequence of hipGraphs with the collectives between the
     G2  g_ed_branch                 frozen emotion discriminator forward + input gradient: does not touch the critic
     G3  d_update_g_critic_chain     critic Adam, critic forward/backward on the generated batch, generator data
                                     gradients down to decoder.pre.2
-    C2  all-gather of pre.2's two gradient factors (mode overlap / gather) -- see below
+    C2  all-gather of pre.2's two gradient factors (modes gather / overlap) -- see below
     G4  g_backward_b                deconvolution + Linear weight gradients, the rest of the backward chain
-    G5  g_p2_wgrad                  pre.2's global weight gradient from the gathered factors
+    G5  g_p2_wgrad                  pre.2's global weight gradient from the gathered factors (inside G4 when C2 is synchronous)
     C3  all-reduce(everything else of the generator / encoder gradient, 2 MB)
     G6  g_update
 
-Step orders (MELO_DP_MODE, default "overlap"):
-  overlap    C1 and C2 are issued asynchronously (RCCL's own stream, ordered behind the engine's by an event) and
-             waited for where their result is needed: C1 runs beside G2 (~250 us of convolutions at cfg2), C2 beside G4
-             (~150 us), so the transfers -- and the ~45 us cross-stream hand-off an asynchronous collective costs, measured
-             in round 1 -- hide behind compute that does not depend on them.  C3 is small and synchronous.
-  gather     the same collectives, all synchronous on the engine's stream in program order (no overlap).
+Step orders (MELO_DP_MODE; default "auto" = "overlap" from 8 ranks up, "gather" below):
+  gather     every collective synchronous, on the engine's stream, in program order.
+  overlap    C2 -- the only transfer large enough to be worth it, 18 MB received per rank at N = 8 -- is issued
+             asynchronously (RCCL's own stream, ordered behind the engine's by an event) and runs beside G4 (~150 us of
+             weight gradients that do not depend on it); C1 and C3 stay synchronous.
   allreduce  one synchronous all-reduce per optimiser, no factor gather.
+Why not everything asynchronous: measured on one MI355X with a 1-rank RCCL group (the transfers take no time there, so
+what shows is the price of the mechanism): no collectives 1.176 ms/step, allreduce 1.214, gather 1.245, C1 and C2 both
+asynchronous 1.345 -- and 1.352 with the collectives synchronous but G2 / G4 forked onto a side stream instead.  A
+cross-stream fork + join around a hipGraph launch costs ~50 us on this platform whichever side carries the collective,
+so overlap pays only for a transfer that takes longer than that: C2 at N = 8 (~75-150 us expected), not C1 (~30 us).
 
 Factor gather: decoder.pre.2.weight is 16.8 of the generator's 18.8 MB and its gradient is d_p2^T a_p0, so the ranks
 all-gather those two per-sample factors (2.2 MB per rank) and each computes the global batch's weight gradient itself
@@ -47,7 +51,7 @@ from __future__ import annotations
 
 import os
 
-MODES = ("overlap", "gather", "allreduce")
+MODES = ("auto", "overlap", "gather", "allreduce")
 
 
 class DataParallel:
@@ -57,9 +61,11 @@ class DataParallel:
         self.engine, self.world, self.dist, self.group = engine, int(world_size), dist, group
         self.active = dist is not None and (self.world > 1 or force_collectives)
         self._dry = os.environ.get("MELO_DP_DRY") == "1"      # rehearsal: the N > 1 step order without the collectives
-        self.mode = os.environ.get("MELO_DP_MODE", "overlap")
+        self.mode = os.environ.get("MELO_DP_MODE", "auto")
         if self.mode not in MODES:
             raise ValueError(f"MELO_DP_MODE={self.mode}: expected one of {MODES}")
+        if self.mode == "auto":
+            self.mode = "overlap" if self.world >= 8 else "gather"
         if self.mode != "allreduce" and not hasattr(engine, "enable_p2_gather"):
             self.mode = "allreduce"
         if self.active and self.mode != "allreduce":
@@ -179,24 +185,26 @@ class DataParallel:
 
     def _step(self, use_graph: bool, g_step: bool):
         e = self.engine
-        asyn = self.mode == "overlap"
         if not g_step:
             e.run("d_backward_rng", use_graph)        # Philox draw (noise, alpha, dropout masks) + D fwd/bwd
             self.allreduce_d()
             e.run("d_update", use_graph)
             return
         e.run("dg_forward_d_backward_rng", use_graph)
-        self.allreduce_d(async_op=asyn)               # C1 ...
-        e.run("g_ed_branch", use_graph)               # ... beside the emotion discriminator's forward / backward
-        self._wait()
+        self.allreduce_d()                            # C1
+        e.run("g_ed_branch", use_graph)
         e.run("d_update_g_critic_chain", use_graph)
         if self.mode == "allreduce":
             e.run("g_backward_b", use_graph)
             self.allreduce_g()
+        elif self.mode == "gather":
+            self.gather_p2()                          # C2, synchronous
+            e.run("g_backward_p2b", use_graph)        # pre.2's global weight gradient shares the weight-gradient launch
+            self.allreduce_g_rest()
         else:
-            self.gather_p2(async_op=asyn)             # C2 ...
+            self.gather_p2(async_op=True)             # C2 ...
             e.run("g_backward_b", use_graph)          # ... beside the weight gradients and the rest of the backward chain
             self._wait()
             e.run("g_p2_wgrad", use_graph)
-            self.allreduce_g_rest()
+            self.allreduce_g_rest()                   # C3
         e.run("g_update", use_graph)

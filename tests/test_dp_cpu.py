@@ -76,17 +76,22 @@ def _worker(rank, port, out):
             assert torch.equal(eng.D.grad, d_sum), "critic update before its all-reduce finished"
         elif name == "g_backward_b":
             eng.GE.grad.copy_(fg)
-        elif name == "g_p2_wgrad":                   # every rank's factors, in rank order
+        elif name in ("g_p2_wgrad", "g_backward_p2b"):   # every rank's factors, in rank order
             want = torch.cat([torch.full((3, 4), float(r + 1)) for r in range(WORLD)])
             assert torch.equal(eng.d_p2_all, want) and torch.equal(eng.a_p0_all[:, 0], 10 * want[:, 0])
+            if name == "g_backward_p2b":
+                eng.GE.grad.copy_(fg)
             eng.GE.grad[:NBIG].copy_(g_sum[:NBIG])   # what the engine computes from them: the global-batch gradient
         elif name == "g_update":
             assert torch.equal(eng.GE.grad, g_sum), "generator update with a partially reduced gradient"
     eng.run = run
-    gather_order = ["dg_forward_d_backward_rng", "g_ed_branch", "d_update_g_critic_chain", "g_backward_b", "g_p2_wgrad", "g_update"]
-    orders = {"overlap": gather_order, "gather": gather_order,
+    head = ["dg_forward_d_backward_rng", "g_ed_branch", "d_update_g_critic_chain"]
+    orders = {"overlap": head + ["g_backward_b", "g_p2_wgrad", "g_update"], "gather": head + ["g_backward_p2b", "g_update"],
               "allreduce": ["dg_forward_d_backward_rng", "g_ed_branch", "d_update_g_critic_chain", "g_backward_b", "g_update"]}
     for mode, order in orders.items():
+        os.environ["MELO_DP_MODE"] = mode
+        os.environ["MELO_DP_MODE"] = "auto"
+        assert DataParallel(eng, 8, dist).mode == "overlap" and DataParallel(eng, WORLD, dist).mode == "gather"
         os.environ["MELO_DP_MODE"] = mode
         dp = DataParallel(eng, WORLD, dist)
         assert dp.mode == mode

@@ -209,7 +209,7 @@ def test_two_engines_as_two_ranks_full_step(mode, monkeypatch):
     Sd = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
     for e, (real, numeric, latent, emot) in zip(engs, shards):
         Sr = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
-        rd = O.d_step(Sr, real, latent, numeric, e.noise_d.cpu(), e.alpha.cpu(), [keep(m) for m in e.dmask_d])
+        rd = O.d_step(Sr, real, latent, numeric, e.noise_d.cpu(), e.alpha.cpu().view(-1, 1, 1), [keep(m) for m in e.dmask_d])
         gd.append(rd["grads"])
     mean_d = {k: sum(g[k] for g in gd) / WORLD for k in gd[0]}
     Sd.opt_D.step(Sd.PD, mean_d)                                   # the critic every rank holds after C1 + d_update
@@ -231,10 +231,12 @@ def test_two_engines_as_two_ranks_full_step(mode, monkeypatch):
         if k in ("G.decoder.deconv.0.bias", "G.decoder.deconv.3.bias"):
             continue
         assert rel_err(e0.GE.g[k].cpu() / WORLD, ref) < 5e-3, (mode, "GE", k, rel_err(e0.GE.g[k].cpu() / WORLD, ref))
-    # first Adam step on the averaged gradient: -lr * sign(g) wherever the gradient is well-conditioned
+    # first Adam step on the averaged gradient: -lr * g / (|g| + eps) wherever the gradient is well-conditioned
     for fp, mean, P0, lr in ((e0.D, mean_d, S.PD, e0.lr_d), (e0.GE, mean_g, S.PGE, e0.lr_g)):
         for k, ref in mean.items():
+            if k in ("G.decoder.deconv.0.bias", "G.decoder.deconv.3.bias", "real_fake.bias", "real_fake.weight", "fc.1.bias"):
+                continue                # zero-gradient parameters: rounding noise (tests/test_engine_gpu.py)
             mask = ref.abs() >= 0.1 * ref.pow(2).mean().sqrt()
             upd = fp.p[k].cpu() - P0[k]
-            want = -lr * torch.sign(ref)
+            want = -lr * ref / (ref.abs() + 1e-8)
             assert float((upd - want)[mask].abs().max()) <= 2e-2 * lr, (mode, k)
