@@ -94,6 +94,20 @@ int mg_conv1d_scatter2(const float* x, const float* w, float* y,
                        int w_sn, int w_sc, long xbs, long ybs,
                        const mg_epilogue* epi, void* work, size_t work_bytes, mg_stream_t stream);
 
+/* ---- the stride-2, 5-tap window GEMMs on 16x16x4 MFMA tiles (csrc/conv16_mfma.hip) ----
+ * The same arithmetic as mg_conv1d_gather(stride 2, K 5) [transposed = 0: nn.Conv1d(k5,s2,p2) forward,
+ * src/gan/models.py:141-145, src/ae/model.py:11-19; nn.ConvTranspose1d data-gradient] and mg_conv1d_scatter2
+ * [transposed = 1: nn.ConvTranspose1d(k5,s2,p2,op1) forward, src/gan/models.py:56-62; Conv1d stride-2 data-gradient,
+ * Tout = 2*Tin or 2*Tin-1] in 64x32 / 32x32 output tiles with the whole channel reduction inside each workgroup: no
+ * split-K workspace, no second launch, bitwise run-to-run reproducible.  Weights in the WQ layout
+ *     wq[((c/4)*5 + k)*N + n][c%4] = W(n, c, k)        (N output columns, c reduction channel, Cin % 16 == 0, N % 32 == 0)
+ * which mg_wq_relayout derives from a reference-layout tensor (W(n,c,k) = w[n*w_sn + c*w_sc + k]) and mg_adam_flat_wq
+ * keeps current after every optimiser step.  mg_conv16_supported tells whether a shape is covered (else use the calls above). */
+int mg_wq_relayout(const float* w, float* wq, int N, int Cc, int K, int w_sn, int w_sc, mg_stream_t stream);
+int mg_conv16_supported(int B, int Tin, int Cin, int N, int transposed, int Tout);
+int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+              long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream);
+
 /* ---- skinny GEMM for nn.Linear forward / data-gradient with few rows (M = batch) ----
  *   y[M,N] = EPI( x[M,K] @ W^T ),  W(n,c) = w[n*w_sn + c*w_sc], one of the strides must be 1:
  *   nn.Linear forward (src/gan/models.py:24-26,47-49,151; feature_encoder.py:23,38; ed_model.py:61,78,90):
@@ -289,6 +303,21 @@ int mg_adam_flat_ticked(float* p, const float* g, float* m, float* v, long n,
                         float lr, float beta1, float beta2, float eps, float weight_decay,
                         const double* state, float grad_scale, const float* gs_dev, uint64_t* rng_step,
                         mg_stream_t stream);
+/* The update that ALSO keeps WQ-layout copies (mg_conv16) of some weight tensors current: entry = a dense tensor
+ * W(n,c,k) = w[n*w_sn + c*w_sc + k] at [start, start + N*Cc*K) of the flat buffer, in (N,Cc,K) order (w_sn = Cc*K,
+ * w_sc = K) or (Cc,N,K) order (w_sn = K, w_sc = N*K); dst (N*Cc*K floats) receives the updated values in WQ order.
+ * state_ticked: the Adam state was advanced by mg_rng_fill_tick(2) (rng_step, if not NULL, is advanced here); otherwise
+ * it is advanced by this call. */
+#define MG_MAX_WQ_ENTRIES 8
+typedef struct mg_wq_entry {
+    long start;
+    int N, Cc, K, w_sn, w_sc;
+    float* dst;
+} mg_wq_entry;
+int mg_adam_flat_wq(float* p, const float* g, float* m, float* v, long n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    double* state, float grad_scale, const float* gs_dev, int state_ticked, uint64_t* rng_step,
+                    const mg_wq_entry* table, int n_table, mg_stream_t stream);
 /* out[0] = sqrt(sum g^2) ; out[1] = min(1, max_norm/(norm+1e-6))  (clip_grad_norm_, train_ae.py:121) */
 int mg_grad_norm_clip(const float* g, long n, float max_norm, float* out, void* work, size_t work_bytes,
                       mg_stream_t stream);

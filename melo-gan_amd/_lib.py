@@ -30,6 +30,13 @@ class WgradJob(C.Structure):
 
 MAX_WGRAD_JOBS = 8
 
+
+class WqEntry(C.Structure):
+    _fields_ = [("start", i64), ("N", i32), ("Cc", i32), ("K", i32), ("w_sn", i32), ("w_sc", i32), ("dst", vp)]
+
+
+MAX_WQ_ENTRIES = 8
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
 SIGNATURES = {
     "mg_version": (i32, []),
@@ -37,6 +44,9 @@ SIGNATURES = {
     "mg_conv_workspace_bytes": (sz, [i32, i32, i32]),
     "mg_conv1d_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_conv1d_scatter2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, sz, vp]),
+    "mg_wq_relayout": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mg_conv16_supported": (i32, [i32, i32, i32, i32, i32, i32]),
+    "mg_conv16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
     "mg_linear_workspace_bytes": (sz, [i32, i32, i32]),
     "mg_linear": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_conv_tile_config": (i32, [i64, i32, i32]),
@@ -77,6 +87,7 @@ SIGNATURES = {
     "mg_rng_fill_tick2": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, vp, f32, f32, vp]),
     "mg_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
     "mg_adam_flat_ticked": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp, vp]),
+    "mg_adam_flat_wq": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, i32, vp, vp, i32, vp]),
     "mg_grad_norm_workspace_bytes": (sz, [i64]),
     "mg_grad_norm_clip": (i32, [vp, i64, f32, vp, vp, sz, vp]),
     "mg_reparam_fwd": (i32, [vp, vp, vp, vp, i64, vp]),

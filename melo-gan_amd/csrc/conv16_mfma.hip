@@ -1,0 +1,383 @@
+// Stride-2, 5-tap window GEMMs (Conv1d stride 2 forward, ConvTranspose1d stride 2 forward and both data-gradients --
+// every convolution of the critic and of the generator) on v_mfma_f32_16x16x4_f32, in 32*RT x 32 output tiles.
+//
+// Why a second window-GEMM kernel.  conv_mfma.hip's 64x64 tiles (one 32x32x2 MFMA tile per wave) leave the B = 64
+// layers with 64-128 workgroups for 256 CUs: it splits the channel reduction over workgroups and pays a second launch
+// that sums the partial slabs (13 such launches per training step, ~5 us each, around a ~13-us kernel whose MFMA time
+// is 4.3 us), and the 3B-row critic layers land on 384 workgroups -- 1.5 per CU, i.e. 75 % of the chip at best.
+// A 16x16 MFMA tile is a quarter of a 32x32 one at the same FLOP rate (32 cycles for 2048 FLOP against 64 for 4096), so
+// a 4-wave workgroup can own a 64x32 (RT = 2) or 32x32 (RT = 1) tile: 256-1024 workgroups for the same layers with the
+// WHOLE channel reduction inside each -- no split, no partial slabs, no finish launch, bitwise run-to-run
+// reproducible by construction -- and the 3B layers get 768 workgroups = 3 per CU.
+//
+// Weights come in the "WQ" layout, wq[((c/4)*5 + k)*N + n][c%4]: the four channels of a quad contiguous per (tap,
+// output column), which IS the LDS image (20 planes of 32 columns x 16 B per 16-channel chunk), so staging a chunk's
+// weights is 640 plain 16-byte copies.  The optimiser writes this layout next to the reference's (mg_adam_flat_wq), once
+// per update and per direction a convolution is used in; mg_wq_relayout fills it from a state_dict tensor.
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D: column = lane & 15, rows 4 * (lane >> 4) + r.  Lane (i, kq) reads channel quad kq of its window row / weight
+// column with ONE ds_read_b128 and feeds element s of it to MFMA s of the chunk's tap: k-slot kq <-> channel 4 kq + s on
+// both operands.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Conv16P {
+    const float* x;
+    const float* wq;
+    float* y;
+    int B, Tin, Cin, Tm, Tout, N;
+    long xbs, ybs;
+    int x_bytes, w_bytes;     // extents for the buffer descriptors (host checked < 2^31)
+    int tt_log2, n_ttiles;
+    unsigned nt_magic;
+    mg_epilogue e;
+};
+
+constexpr int K5 = 5;
+constexpr int BKC = 16;                 // channels per chunk
+// window row pitch in floats, chosen so that the 16 lanes of every ds_read_b128 group -- 8 rows x 2 channel quads --
+// hit 16 different bank quads: 20 for rows two apart (stride-2 gather), 24 for consecutive rows (transposed form)
+template <bool TR2> struct PitchOf { static constexpr int value = TR2 ? 24 : 20; };
+constexpr int BN = 32;
+constexpr int WPLANE = BN * 4;          // floats of one (quad, tap) plane: 32 columns x 4 channels
+constexpr int WSLAB = 4 * K5 * WPLANE;  // 20 planes = 10 KB per chunk
+constexpr int MAXX = 3;                 // window float4 slots per thread (<= 192 window rows per tile)
+constexpr int NWU = 3;                  // weight float4 slots per thread (640 per chunk over 256 threads)
+
+template <bool TR2, int RT>
+__global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
+    constexpr int BM = 32 * RT;
+    constexpr int SX = PitchOf<TR2>::value;
+    constexpr int SA = TR2 ? 1 : 2;     // window rows between consecutive tile positions
+    constexpr int NR = TR2 ? 3 : 5;     // window rows one position touches
+    constexpr int NPH = TR2 ? 2 : 1;    // output phases (t = 2u, 2u + 1) of the transposed form
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, kq = lane >> 4;
+    const int TT = 1 << p.tt_log2, TB = BM >> p.tt_log2;
+    const int R = (TT - 1) * SA + NR;
+    const int nrows = TB * R;
+    const int xs_floats = nrows * SX;
+    const int buf_floats = xs_floats + WSLAB;
+
+    const int mtile = blockIdx.x;
+    int mq = (int)__umulhi((unsigned)mtile, p.nt_magic);
+    if ((mq + 1) * p.n_ttiles <= mtile) ++mq;
+    const int b0 = mq * TB;
+    const int t0 = (mtile - mq * p.n_ttiles) * TT;
+    const int n0 = blockIdx.y * BN;
+    const int tin0 = TR2 ? (t0 - 1) : (2 * t0 - 2);
+
+    auto lds4 = [&](int off) { return reinterpret_cast<f32x4*>(__builtin_assume_aligned(smem + off, 16)); };
+
+    int abase[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int im = (wm * RT + rt) * 16 + li;
+        const int seg = im >> p.tt_log2, tl = im & (TT - 1);
+        abase[rt] = (seg * R + tl * SA) * SX + 4 * kq;
+    }
+    const int bbase = xs_floats + kq * K5 * WPLANE + (16 * wn + li) * 4;
+
+    f32x4 acc[NPH][RT];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[ph][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging plan: global -> registers (a chunk ahead) -> the other LDS buffer ----
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wq), 0, p.w_bytes, 0x00020000);
+    const int sink = 2 * buf_floats + 4 * tid;      // per-thread 16-B sink for slots without data
+    unsigned xo[MAXX];
+    int xl[MAXX], xd[MAXX];
+#pragma unroll
+    for (int j = 0; j < MAXX; ++j) {
+        const int idx = tid + 256 * j;
+        xo[j] = 0x80000000u;          // beyond num_records: the hardware returns 0
+        xl[j] = sink;
+        xd[j] = 0;
+        if (idx < nrows * 4) {
+            const int row = idx >> 2, q = idx & 3;
+            const int seg = (TB == 1) ? 0 : row / R, r = row - seg * R;
+            const int b = b0 + seg, tin = tin0 + r;
+            xl[j] = row * SX + 4 * q;
+            xd[j] = buf_floats;
+            if (b < p.B && tin >= 0 && tin < p.Tin)
+                xo[j] = ((unsigned)b * (unsigned)p.xbs + (unsigned)(tin * p.Cin + 4 * q)) * 4u;
+        }
+    }
+    unsigned wo[NWU];
+    int wl[NWU], wd[NWU];
+#pragma unroll
+    for (int i = 0; i < NWU; ++i) {
+        const int u = tid + 256 * i;
+        wo[i] = 0x80000000u;
+        wl[i] = sink;
+        wd[i] = 0;
+        if (u < 4 * K5 * BN) {
+            const int pl = u >> 5, n = u & 31;
+            wl[i] = xs_floats + u * 4;
+            wd[i] = buf_floats;
+            if (n0 + n < p.N) wo[i] = ((unsigned)pl * (unsigned)p.N + (unsigned)(n0 + n)) * 16u;
+        }
+    }
+    const unsigned wchunk = (unsigned)(K5 * p.N) * 16u;     // bytes between consecutive channel quads' plane groups
+    f32x4 xr[MAXX], wr[NWU];
+    auto bload = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned soff) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    };
+    auto load_chunk = [&](int c0) {
+        const unsigned xs = 4u * (unsigned)c0, ws = (unsigned)(c0 >> 2) * wchunk;
+#pragma unroll
+        for (int j = 0; j < MAXX; ++j) xr[j] = bload(xrsrc, xo[j], xs);
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) wr[i] = bload(wrsrc, wo[i], ws);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MAXX; ++j) *lds4(xl[j] + (buf ? xd[j] : 0)) = xr[j];
+#pragma unroll
+        for (int i = 0; i < NWU; ++i) *lds4(wl[i] + (buf ? wd[i] : 0)) = wr[i];
+    };
+
+    // One chunk = 5 slots of 4*RT MFMAs: slot q pairs tap k with a window-row offset ro (and, transposed, a phase):
+    //   gather     : (k, ro) = (q, q)
+    //   transposed : phase 0 (t = 2u):   k = 0 <- row u+1, k = 2 <- row u, k = 4 <- row u-1
+    //                phase 1 (t = 2u+1): k = 1 <- row u+1, k = 3 <- row u            (window row 0 is u-1)
+    auto slot_tap = [](int q) { return q; };
+    auto slot_row = [](int q) { return TR2 ? (q < 2 ? 2 : (q < 4 ? 1 : 0)) : q; };
+    auto slot_ph = [](int q) { return TR2 ? (q & 1) : 0; };
+    auto frag_read = [&](int boff, int q, f32x4 (&A)[RT], f32x4& Bv) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) A[rt] = *lds4(boff + abase[rt] + slot_row(q) * SX);
+        Bv = *lds4(boff + bbase + slot_tap(q) * WPLANE);
+    };
+    f32x4 fa[2][RT], fb[2];
+    auto chunk = [&](auto parity, int c_next2, bool more) {
+        constexpr int P = decltype(parity)::value;
+        const int cur = P ? buf_floats : 0;
+        frag_read(cur, 0, fa[0], fb[0]);
+        if (more) store_chunk(1 - P);           // registers hold the next chunk: into the other buffer ...
+        load_chunk(c_next2);                    // ... and reload them with the chunk after that (clamped: harmless re-read)
+#pragma unroll
+        for (int q = 0; q < K5; ++q) {
+            if (q + 1 < K5) frag_read(cur, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+            const int ph = slot_ph(q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[ph][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][rt][s], fb[q & 1][s], acc[ph][rt], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+
+    const int c_last = p.Cin - BKC;
+    load_chunk(0);
+    store_chunk(0);
+    load_chunk(min(BKC, c_last));
+    __syncthreads();
+    for (int c0 = 0;;) {
+        chunk(std::integral_constant<int, 0>{}, min(c0 + 2 * BKC, c_last), c0 + BKC < p.Cin);
+        c0 += BKC;
+        if (c0 >= p.Cin) break;
+        chunk(std::integral_constant<int, 1>{}, min(c0 + 2 * BKC, c_last), c0 + BKC < p.Cin);
+        c0 += BKC;
+        if (c0 >= p.Cin) break;
+    }
+
+    // ---- epilogue: lane holds column n, rows 4*kq + r of each 16x16 tile ----
+    const mg_epilogue& E = p.e;
+    const int n = n0 + 16 * wn + li;
+    if (n >= p.N) return;
+    const float bias = E.bias ? E.bias[n] : 0.f;
+    const float scale = E.scale ? E.scale[n] : 1.f, shift = E.scale ? E.shift[n] : 0.f;
+    const float gscale = E.gscale ? E.gscale[n] : 1.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            f32x4 a = acc[ph][rt];
+            unsigned di[4], yi[4];
+            bool ok[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int im = (wm * RT + rt) * 16 + 4 * kq + r;
+                const int seg = im >> p.tt_log2, tl = im & (TT - 1);
+                const int b = b0 + seg, t = t0 + tl;
+                const int tout = TR2 ? 2 * t + ph : t;
+                di[r] = (unsigned)((b * p.Tout + tout) * p.N + n);
+                yi[r] = (unsigned)(b * (int)p.ybs + tout * p.N + n);
+                ok[r] = b < p.B && t < p.Tm && tout < p.Tout;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = (a[r] + bias) * scale + shift;
+            if (E.zout) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[r]) E.zout[di[r]] = a[r];
+            }
+            if (E.act == MG_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = mg_act(MG_ACT_RELU, a[r]);
+            } else if (E.act == MG_ACT_LRELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = mg_act(MG_ACT_LRELU, a[r]);
+            } else if (E.act == MG_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = mg_act(MG_ACT_GELU, a[r]);
+            } else if (E.act == MG_ACT_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = mg_act(MG_ACT_TANH, a[r]);
+            }
+            if (E.gref) {
+                if (E.gact == MG_ACT_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_RELU, E.gref[di[r]]);
+                } else if (E.gact == MG_ACT_LRELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_LRELU, E.gref[di[r]]);
+                } else if (E.gact == MG_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_GELU, E.gref[di[r]]);
+                } else if (E.gact == MG_ACT_TANH) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_TANH, E.gref[di[r]]);
+                }
+            }
+            if (E.emul) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[r]) a[r] *= E.emul[di[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] *= gscale;
+            if (E.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[r]) a[r] += p.y[yi[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ok[r]) p.y[yi[r]] = a[r];
+        }
+}
+
+// wq[((c/4)*K + k)*N + n][c%4] = w[n*sn + c*sc + k]
+__global__ void wq_relayout_kernel(const float* __restrict__ w, float* __restrict__ wq, int N, int Cc, int K, int sn, int sc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * Cc * K) return;
+    const int e = (int)(i & 3);
+    const long r = i >> 2;
+    const int n = (int)(r % N);
+    const long r2 = r / N;
+    const int k = (int)(r2 % K), q = (int)(r2 / K);
+    wq[i] = w[(long)n * sn + (long)(4 * q + e) * sc + k];
+}
+
+template <bool TR2, int RT>
+int launch16(Conv16P p, hipStream_t stream) {
+    constexpr int BM = 32 * RT;
+    constexpr int SX = PitchOf<TR2>::value;
+    constexpr int SA = TR2 ? 1 : 2;
+    constexpr int NR = TR2 ? 3 : 5;
+    int lg = mg_ilog2_ceil(p.Tm);
+    const int lgbm = mg_ilog2_ceil(BM);
+    if (lg > lgbm) lg = lgbm;
+    p.tt_log2 = lg;
+    const int TT = 1 << lg, TB = BM >> lg;
+    p.n_ttiles = (int)mg_cdiv(p.Tm, TT);
+    p.nt_magic = p.n_ttiles > 1 ? (unsigned)((1ULL << 32) / (unsigned)p.n_ttiles) : 0xFFFFFFFFu;
+    const int R = (TT - 1) * SA + NR;
+    if (TB * R * 4 > 256 * MAXX) return MG_EUNSUP;        // too many window rows for the staging plan (tiny Tm)
+    const size_t lds = 2 * ((size_t)TB * R * SX + WSLAB) * sizeof(float) + 256 * 4 * sizeof(float);
+    auto kernel = &conv16_kernel<TR2, RT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            mg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return MG_EHIP;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.n_ttiles * mg_cdiv(p.B, TB)), (unsigned)mg_cdiv(p.N, BN));
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, p);
+    MG_CHECK_LAUNCH("conv16");
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" int mg_wq_relayout(const float* w, float* wq, int N, int Cc, int K, int w_sn, int w_sc, mg_stream_t stream) {
+    MG_CHECK_ARG(w && wq && N > 0 && Cc > 0 && K > 0 && Cc % 4 == 0 && w_sn > 0 && w_sc > 0, "mg_wq_relayout: bad args");
+    const long total = (long)N * Cc * K;
+    hipLaunchKernelGGL(wq_relayout_kernel, dim3((unsigned)mg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wq, N, Cc, K,
+                       w_sn, w_sc);
+    MG_CHECK_LAUNCH("wq_relayout");
+    return MG_OK;
+}
+
+// rows per tile the planner picks: 64 unless that leaves most of the chip idle
+static int pick_rt(long m_rows, int N) {
+    if (const char* f = getenv("MG_CONV16_RT")) return atoi(f) == 1 ? 1 : 2;
+    return (mg_cdiv(m_rows, 64) * mg_cdiv(N, BN) >= 192) ? 2 : 1;
+}
+
+// 1 if mg_conv16 supports the shape (otherwise the caller uses mg_conv1d_gather / mg_conv1d_scatter2)
+extern "C" int mg_conv16_supported(int B, int Tin, int Cin, int N, int transposed, int Tout) {
+    if (B <= 0 || Tin <= 0 || Cin % BKC || N % BN) return 0;
+    const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
+    if (Tm < 4) return 0;                                      // tiles of a few positions: not worth a plan
+    if (transposed && !(Tout == 2 * Tin || Tout == 2 * Tin - 1)) return 0;
+    const long xe = (long)B * Tin * Cin * 4, we = (long)N * Cin * K5 * 4, ye = (long)B * (transposed ? Tout : Tm) * N;
+    if (!(xe < (1L << 31) && we < (1L << 31) && ye < (1L << 31))) return 0;
+    // window rows of one tile must fit the staging plan (MAXX float4 slots per thread)
+    const int BM = 32 * pick_rt((long)B * Tm, N);
+    int lg = mg_ilog2_ceil(Tm);
+    if (lg > mg_ilog2_ceil(BM)) lg = mg_ilog2_ceil(BM);
+    const int TT = 1 << lg, TB = BM >> lg, R = (TT - 1) * (transposed ? 1 : 2) + (transposed ? 3 : 5);
+    return TB * R * 4 <= 256 * MAXX;
+}
+
+extern "C" int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+                         long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream) {
+    MG_CHECK_ARG(x && wq && y, "mg_conv16: null tensor");
+    const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
+    if (!transposed) Tout = Tm;
+    MG_CHECK_ARG(mg_conv16_supported(B, Tin, Cin, N, transposed, Tout), "mg_conv16: unsupported shape B=%d Tin=%d Cin=%d N=%d", B, Tin, Cin, N);
+    Conv16P p{};
+    p.x = x; p.wq = wq; p.y = y;
+    p.B = B; p.Tin = Tin; p.Cin = Cin; p.Tm = Tm; p.Tout = Tout; p.N = N;
+    p.xbs = xbs ? xbs : (long)Tin * Cin;
+    p.ybs = ybs ? ybs : (long)Tout * N;
+    const long xb = ((long)(B - 1) * p.xbs + (long)Tin * Cin) * 4, yb = (long)(B - 1) * p.ybs + (long)Tout * N;
+    MG_CHECK_ARG(xb < (1L << 31) && yb < (1L << 31) && p.ybs < (1L << 31), "mg_conv16: tensor exceeds the 2^31 limit");
+    p.x_bytes = (int)xb;
+    p.w_bytes = (int)((long)N * Cin * K5 * 4);
+    if (epi) {
+        p.e = *epi;
+        MG_CHECK_ARG(!(p.e.scale && !p.e.shift), "epilogue: scale without shift");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int rt = pick_rt((long)B * Tm, N);
+    int rc;
+    if (transposed) rc = rt == 2 ? launch16<true, 2>(p, s) : launch16<true, 1>(p, s);
+    else rc = rt == 2 ? launch16<false, 2>(p, s) : launch16<false, 1>(p, s);
+    if (rc == MG_EUNSUP) mg_set_error("mg_conv16: Tm=%d needs more window rows than the staging plan holds", Tm);
+    return rc;
+}

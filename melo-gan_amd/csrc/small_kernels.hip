@@ -720,10 +720,14 @@ __global__ void adam_advance_kernel(double* state, double beta1, double beta2) {
         state[2] *= beta2;
     }
 }
+// WQ copies kept current by the update (include/melo_gan_hip.h, mg_conv16): for a weight tensor W(n,c,k) =
+// w[n*sn + c*sc + k] living at [start, start + N*Cc*K) of the flat parameter buffer, dst[((c/4)*K + k)*N + n][c%4] = W(n,c,k).
+struct WqTable { mg_wq_entry e[MG_MAX_WQ_ENTRIES]; int n; long lo, hi; };
+
 __global__ void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
                                   float wd, const double* __restrict__ state, float grad_scale,
-                                  const float* __restrict__ gs_dev, unsigned long long* bump) {
+                                  const float* __restrict__ gs_dev, unsigned long long* bump, const WqTable wq) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (bump && i == 0) bump[0] += 1;         // the Philox step counter of the draws this update consumed
     if (i >= n) return;
@@ -741,7 +745,21 @@ __global__ void adam_apply_kernel(float* __restrict__ p, const float* __restrict
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    if (i >= wq.lo && i < wq.hi) {
+        for (int t = 0; t < wq.n; ++t) {
+            const mg_wq_entry& e = wq.e[t];
+            const long L = i - e.start;
+            if (L < 0 || L >= (long)e.N * e.Cc * e.K) continue;
+            const int k = (int)(L % e.K);
+            const long r = L / e.K;
+            int nn, c;
+            if (e.w_sc == e.K) { nn = (int)(r / e.Cc); c = (int)(r % e.Cc); }       // w[n][c][k]
+            else { c = (int)(r / e.N); nn = (int)(r % e.N); }                        // w[c][n][k]
+            e.dst[((long)((c >> 2) * e.K + k) * e.N + nn) * 4 + (c & 3)] = pi;
+        }
+    }
 }
 
 __global__ __launch_bounds__(1024) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* part) {
@@ -1172,7 +1190,7 @@ int mg_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr,
     MG_CHECK_ARG(p && g && m && v && state && n > 0, "mg_adam_flat: bad args");
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST, state, (double)beta1, (double)beta2);
     hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, (const double*)state, grad_scale, gs_dev, (unsigned long long*)nullptr);
+                       weight_decay, (const double*)state, grad_scale, gs_dev, (unsigned long long*)nullptr, WqTable{});
     MG_CHECK_LAUNCH("adam_flat");
     return MG_OK;
 }
@@ -1183,8 +1201,34 @@ int mg_adam_flat_ticked(float* p, const float* g, float* m, float* v, long n, fl
     /* rng_step may be NULL: of the two updates one fused draw serves (mg_rng_fill_tick2) only one advances the counter */
     MG_CHECK_ARG(p && g && m && v && state && n > 0, "mg_adam_flat_ticked: bad args");
     hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, state, grad_scale, gs_dev, (unsigned long long*)rng_step);
+                       weight_decay, state, grad_scale, gs_dev, (unsigned long long*)rng_step, WqTable{});
     MG_CHECK_LAUNCH("adam_flat_ticked");
+    return MG_OK;
+}
+
+int mg_adam_flat_wq(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, double* state, float grad_scale, const float* gs_dev,
+                    int state_ticked, uint64_t* rng_step, const mg_wq_entry* table, int n_table, mg_stream_t stream) {
+    MG_CHECK_ARG(p && g && m && v && state && n > 0, "mg_adam_flat_wq: bad args");
+    MG_CHECK_ARG(n_table >= 0 && n_table <= MG_MAX_WQ_ENTRIES && (n_table == 0 || table), "mg_adam_flat_wq: bad table");
+    WqTable t{};
+    t.n = n_table;
+    t.lo = n; t.hi = 0;
+    for (int i = 0; i < n_table; ++i) {
+        const mg_wq_entry& e = table[i];
+        const long cnt = (long)e.N * e.Cc * e.K;
+        MG_CHECK_ARG(e.dst && e.N > 0 && e.Cc > 0 && e.Cc % 4 == 0 && e.K > 0 && e.start >= 0 && e.start + cnt <= n &&
+                     ((e.w_sc == e.K && e.w_sn == e.Cc * e.K) || (e.w_sn == e.K && e.w_sc == e.N * e.K)),
+                     "mg_adam_flat_wq: table entry %d is not a dense (N,C,K) or (C,N,K) tensor inside the flat buffer", i);
+        t.e[i] = e;
+        if (e.start < t.lo) t.lo = e.start;
+        if (e.start + cnt > t.hi) t.hi = e.start + cnt;
+    }
+    if (!state_ticked)
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST, state, (double)beta1, (double)beta2);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (const double*)state, grad_scale, gs_dev, (unsigned long long*)rng_step, t);
+    MG_CHECK_LAUNCH("adam_flat_wq");
     return MG_OK;
 }
 

@@ -94,6 +94,8 @@ class DataParallel:
             # the broadcasts are ordered on the launching stream only; the step's graphs replay on the engine's stream
             import torch
             torch.cuda.synchronize()
+        if hasattr(self.engine, "params_changed"):
+            self.engine.params_changed()         # derived copies (WQ-layout conv weights, folded emotion discriminator)
 
     # ---- graph capture before the first collective ---------------------------------------------------------
     def prepare(self, use_graph: bool = True):
@@ -119,6 +121,7 @@ class DataParallel:
         torch.cuda.synchronize()
         for t, v in zip(keep, saved):
             t.copy_(v)
+        e.params_changed()
         e.num_batches_tracked, (e.D.ticked, e.GE.ticked) = nbt, ticked
         torch.cuda.synchronize()
         e.capture_locked = True

@@ -291,10 +291,69 @@ class GanEngine:
         # (Forked side streams for independent branches of a step were implemented and measured in round 1: every
         # fork/join cost more cross-queue latency than the overlap returned once the kernels filled the chip -- 1.70 ms
         # single-stream vs 1.73-1.82 -- and were removed; independent launches of one kernel share a launch instead.)
+        self._init_wq()
         self.world_size = 1
         self.p2_world = 0          # > 0: decoder.pre.2's weight gradient comes from all-gathered factors (enable_p2_gather)
         self.capture_locked = False   # DataParallel.prepare(): every graph is captured before the first collective
         self._ed_folded = False
+
+    # -------------------------------------------------------------------------------------
+    # WQ-layout weight copies for conv16 (the stride-2 five-tap convolutions on 16x16 MFMA tiles)
+    # -------------------------------------------------------------------------------------
+    def _init_wq(self):
+        """One WQ copy per (stride-2 convolution, direction it is used in) whose channel counts conv16 covers
+        (reduction channels % 16, output columns % 32): written by the optimiser step itself (mg_adam_flat_wq) and by
+        params_changed() after parameters were written from outside."""
+        self.wq, self._wq_src = {}, []
+        ent = {"D": [], "GE": []}
+
+        def add(fp, key, name, direction, N, Cc, sn, sc):
+            if Cc % 16 or N % 32:
+                return
+            t = torch.zeros(N * Cc * 5, device=self.dev)
+            self.wq[(name, direction)] = t
+            ent[key].append((fp.offsets[name][0], N, Cc, 5, sn, sc, t))
+            self._wq_src.append((fp, name, t, N, Cc, sn, sc))
+        for nm in ("conv.0.weight", "conv.2.weight", "conv.4.weight"):
+            Cout, Cin, _ = self.D.spec[nm]
+            add(self.D, "D", nm, "fwd", Cout, Cin, Cin * 5, 5)           # gather form: n = Cout, c = Cin
+            add(self.D, "D", nm, "dgrad", Cin, Cout, 5, Cin * 5)         # transposed form: n = Cin, c = Cout
+        for nm in ("G.decoder.deconv.0.weight", "G.decoder.deconv.3.weight", "G.decoder.deconv.6.weight"):
+            Cin, Cout, _ = self.GE.spec[nm]
+            add(self.GE, "GE", nm, "fwd", Cout, Cin, 5, Cout * 5)        # transposed form: n = Cout, c = Cin
+            add(self.GE, "GE", nm, "dgrad", Cin, Cout, Cout * 5, 5)      # gather form: n = Cin, c = Cout
+        self._wq_tab = {"D": ops.wq_table(ent["D"]) if ent["D"] else None,
+                        "GE": ops.wq_table(ent["GE"]) if ent["GE"] else None}
+
+    def params_changed(self):
+        """Call after writing parameters other than through the optimiser step (load_state and init_weights do):
+        refreshes the derived copies -- the WQ-layout convolution weights and the folded emotion discriminator."""
+        for fp, name, t, N, Cc, sn, sc in self._wq_src:
+            ops.wq_relayout(fp.p[name], t, N, Cc, 5, sn, sc)
+        self._ed_folded = False
+
+    def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, **epi):
+        """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
+        convT_fwd / convT_dgrad (nn.ConvTranspose1d, weight (Cin,Cout,5)).  conv16 (no split-K, no finish launch) where
+        it covers the shape -- always for the gather form, for the transposed form where the 64x64-tile kernel would
+        have to split the reduction (< 192 workgroups; above that the two are on par, tools/conv16_bench.py)."""
+        w = fp.p[name]
+        transposed = kind in ("conv_dgrad", "convT_fwd")
+        direction = "fwd" if kind.endswith("fwd") else "dgrad"
+        N = w.shape[0] if kind in ("conv_fwd", "convT_dgrad") else w.shape[1]
+        wq = self.wq.get((name, direction))
+        B, Tin, Cin = x.shape
+        odd = transposed and y.shape[1] == 2 * Tin - 1 and kind == "conv_dgrad"
+        if wq is not None and ops.conv16_supported(B, Tin, Cin, N, transposed, (2 * Tin - (1 if odd else 0)) if transposed else 0):
+            if not transposed or -(-B * Tin // 64) * -(-N // 64) < 192:
+                return ops.conv16(x, wq, y, N, transposed, odd=odd, **epi)
+        if kind == "conv_fwd":
+            return ops.conv1d_fwd(x, w, y, 2, **epi)
+        if kind == "conv_dgrad":
+            return ops.conv1d_dgrad(x, w, y, 2, **epi)
+        if kind == "convT_fwd":
+            return ops.convT1d_fwd(x, w, y, **epi)
+        return ops.convT1d_dgrad(x, w, y, **epi)
 
     # -------------------------------------------------------------------------------------
     # state in / out
@@ -308,7 +367,7 @@ class GanEngine:
             self.Gbuf[k].copy_(BG[k])
         for k in self.EDbuf:
             self.EDbuf[k].copy_(BED[k])
-        self._ed_folded = False
+        self.params_changed()
 
     def init_weights(self, seed: int = 42):
         """weights_init (src/gan/utils.py:37-45): N(0, 0.02) on every Conv*/Linear* weight of E_num, G, D,
@@ -332,7 +391,7 @@ class GanEngine:
                 fan_in = math.prod(s[1:])
                 bound = 1.0 / math.sqrt(fan_in)
                 self.ED.p[k].copy_((torch.rand(s, generator=g) * 2 - 1) * bound)
-        self._ed_folded = False
+        self.params_changed()
 
     def state_dicts(self):
         """{'G','E_num','D','ED'} -> reference-format state_dicts (CPU)."""
@@ -461,11 +520,11 @@ class GanEngine:
         ops.linear_fwd(v("lat"), P("decoder.pre.0.weight"), v("a_p0"), bias=P("decoder.pre.0.bias"), act=ACT_RELU)
         ops.linear_fwd(v("a_p0"), P("decoder.pre.2.weight"), v("a_p2"), bias=P("decoder.pre.2.bias"), act=ACT_RELU)
         ops.transpose_bcl_blc(v("a_p2").view(n, 256, self.red), v("y0"))
-        ops.convT1d_fwd(v("y0"), P("decoder.deconv.0.weight"), v("z_d0"), bias=P("decoder.deconv.0.bias"))
+        self._conv5s2("convT_fwd", v("y0"), self.GE, "G.decoder.deconv.0.weight", v("z_d0"), bias=P("decoder.deconv.0.bias"))
         self._bn(v("z_d0"), v("a_d0"), "decoder.deconv.1", 0, train, which)
-        ops.convT1d_fwd(v("a_d0"), P("decoder.deconv.3.weight"), v("z_d3"), bias=P("decoder.deconv.3.bias"))
+        self._conv5s2("convT_fwd", v("a_d0"), self.GE, "G.decoder.deconv.3.weight", v("z_d3"), bias=P("decoder.deconv.3.bias"))
         self._bn(v("z_d3"), v("a_d3"), "decoder.deconv.4", 1, train, which)
-        ops.convT1d_fwd(v("a_d3"), P("decoder.deconv.6.weight"), out, bias=P("decoder.deconv.6.bias"))
+        self._conv5s2("convT_fwd", v("a_d3"), self.GE, "G.decoder.deconv.6.weight", out, bias=P("decoder.deconv.6.bias"))
         if train:
             self.num_batches_tracked += n // self.B
 
@@ -487,9 +546,9 @@ class GanEngine:
         is the numeric embedding of row r % B.  head=False leaves the scoring head to _d_bwd_input(with_head=True),
         which runs it in the same launch as its gradient."""
         P = self.D.p
-        ops.conv1d_fwd(x, P["conv.0.weight"], self.A1[:nb], 2, bias=P["conv.0.bias"], act=ACT_LRELU)
-        ops.conv1d_fwd(self.A1[:nb], P["conv.2.weight"], self.A2[:nb], 2, bias=P["conv.2.bias"], act=ACT_LRELU)
-        ops.conv1d_fwd(self.A2[:nb], P["conv.4.weight"], self.A3[:nb], 2, bias=P["conv.4.bias"], act=ACT_LRELU)
+        self._conv5s2("conv_fwd", x, self.D, "conv.0.weight", self.A1[:nb], bias=P["conv.0.bias"], act=ACT_LRELU)
+        self._conv5s2("conv_fwd", self.A1[:nb], self.D, "conv.2.weight", self.A2[:nb], bias=P["conv.2.bias"], act=ACT_LRELU)
+        self._conv5s2("conv_fwd", self.A2[:nb], self.D, "conv.4.weight", self.A3[:nb], bias=P["conv.4.bias"], act=ACT_LRELU)
         ops.meanT_fwd(self.A3[:nb], self.H[:nb])
         ops.linear_fwd(self.H[:nb], P["fc.1.weight"], self.Fh[:nb], bias=P["fc.1.bias"], act=ACT_LRELU)
         if head:
@@ -506,8 +565,8 @@ class GanEngine:
                           nb_emb=nb if demb is not None else 0)
         ops.linear_dgrad(self.dU[:nb], P["fc.1.weight"], self.dH[:nb])
         ops.meanT_bwd(self.dH[:nb], self.dZ3[:nb], gref=self.A3[:nb], gact=ACT_LRELU)
-        ops.conv1d_dgrad(self.dZ3[:nb], P["conv.4.weight"], self.dZ2[:nb], 2, gref=self.A2[:nb], gact=ACT_LRELU)
-        ops.conv1d_dgrad(self.dZ2[:nb], P["conv.2.weight"], self.dZ1[:nb], 2, gref=self.A1[:nb], gact=ACT_LRELU)
+        self._conv5s2("conv_dgrad", self.dZ3[:nb], self.D, "conv.4.weight", self.dZ2[:nb], gref=self.A2[:nb], gact=ACT_LRELU)
+        self._conv5s2("conv_dgrad", self.dZ2[:nb], self.D, "conv.2.weight", self.dZ1[:nb], gref=self.A1[:nb], gact=ACT_LRELU)
 
     def fold_ed(self):
         """Eval-mode BatchNorm of the frozen ED folded with its conv bias into scale/shift (once)."""
@@ -576,14 +635,14 @@ class GanEngine:
         self._d_fwd(self.X0[:3 * B], 3 * B, self.emb_d, head=False)
         # one backward for [x_hat | real | fake] with ds = [1 | -1/B | +1/B]
         self._d_bwd_input(self.ds_d, 3 * B, self.emb_d, None, with_head=True)
-        ops.conv1d_dgrad(self.dZ1[:B], P["conv.0.weight"], self.gx, 2)
+        self._conv5s2("conv_dgrad", self.dZ1[:B], self.D, "conv.0.weight", self.gx)
         ops.gp_penalty(self.gx, self.TAN0, self.norms, None, self.lambda_gp)      # mean((norm-1)^2): in wgan_d_loss
         # Weight gradients are [real,fake] activations x Wasserstein dZ + tangent activations x penalty dZ; each
         # becomes launchable as soon as its tangent exists (d(lambda*gp)/d(grad_xhat) pushed forward through the
         # masked linear critic).
-        ops.conv1d_fwd(self.TAN0, P["conv.0.weight"], self.TAN1, 2, gref=self.A1[:B], gact=ACT_LRELU)
-        ops.conv1d_fwd(self.TAN1, P["conv.2.weight"], self.TAN2, 2, gref=self.A2[:B], gact=ACT_LRELU)
-        ops.conv1d_fwd(self.TAN2, P["conv.4.weight"], self.TZ3, 2, gref=self.A3[:B], gact=ACT_LRELU)
+        self._conv5s2("conv_fwd", self.TAN0, self.D, "conv.0.weight", self.TAN1, gref=self.A1[:B], gact=ACT_LRELU)
+        self._conv5s2("conv_fwd", self.TAN1, self.D, "conv.2.weight", self.TAN2, gref=self.A2[:B], gact=ACT_LRELU)
+        self._conv5s2("conv_fwd", self.TAN2, self.D, "conv.4.weight", self.TZ3, gref=self.A3[:B], gact=ACT_LRELU)
         # the three convolutions' weight gradients go out as ONE launch (+ one slab reduction) once their tangents
         # exist (ops.wgrad_multi): three launches of ~256 workgroups each plus three reductions before
         ops.wgrad_multi([
@@ -664,7 +723,8 @@ class GanEngine:
     def _adam(self, fp, lr):
         """The optimiser step; after draw_randoms() the Adam state is already advanced (fp.ticked)."""
         ops.adam_flat(fp.data, fp.grad, fp.m, fp.v, fp.state, lr, *self.betas, grad_scale=1.0 / self.world_size,
-                      ticked_rng_step=self.rng_step if fp.ticked is True else None, ticked=bool(fp.ticked))
+                      ticked_rng_step=self.rng_step if fp.ticked is True else None, ticked=bool(fp.ticked),
+                      wq=self._wq_tab["D" if fp is self.D else "GE"])
         fp.ticked = False
 
     def d_update(self):
@@ -718,7 +778,7 @@ class GanEngine:
         self._d_fwd(self.notes, B, self.emb, head=False)
         self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True)
         ops.neg_mean(self.s[:B], self.adv)
-        ops.conv1d_dgrad(self.dZ1[:B], self.D.p["conv.0.weight"], self.dnotes, 2, accumulate=self.ed_mode == "notes")
+        self._conv5s2("conv_dgrad", self.dZ1[:B], self.D, "conv.0.weight", self.dnotes, accumulate=self.ed_mode == "notes")
         # ---- generator backward: the data-gradient chain down to decoder.pre.2, then pre.2's weight gradient -- 89 % of
         # the generator's gradient bytes, all-reduced while g_backward_b runs.  The deconvolutions' weight gradients
         # are not on that chain and wait in g_backward_b, where they widen the window the all-reduce hides in. ----
@@ -726,13 +786,13 @@ class GanEngine:
         if self.dn_dense is not None:      # zero-padded tail rows carry no gradient (models.py:78-81)
             ops.copy_cols(self.dnotes.view(B, -1), 0, self.dn_dense.view(B, -1), 0, self.L3 * self.C)
             dn = self.dn_dense
-        ops.convT1d_dgrad(dn, PG("decoder.deconv.6.weight"), self.d_ad3)
+        self._conv5s2("convT_dgrad", dn, self.GE, "G.decoder.deconv.6.weight", self.d_ad3)
         ops.bn_train_bwd(self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, PG("decoder.deconv.4.weight"), self.bn_mean[1],
                          self.bn_invstd[1], GG("decoder.deconv.4.weight"), GG("decoder.deconv.4.bias"), ACT_RELU)
-        ops.convT1d_dgrad(self.d_zd3, PG("decoder.deconv.3.weight"), self.d_ad0)
+        self._conv5s2("convT_dgrad", self.d_zd3, self.GE, "G.decoder.deconv.3.weight", self.d_ad0)
         ops.bn_train_bwd(self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, PG("decoder.deconv.1.weight"), self.bn_mean[0],
                          self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
-        ops.convT1d_dgrad(self.d_zd0, PG("decoder.deconv.0.weight"), self.d_y0)
+        self._conv5s2("convT_dgrad", self.d_zd0, self.GE, "G.decoder.deconv.0.weight", self.d_y0)
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red), gref=self.a_p2, gact=ACT_RELU)
         # pre.2's weight gradient: launched by g_backward_b with the other weight gradients, or -- data parallel, factor

@@ -195,6 +195,49 @@ def convT1d_dgrad(dy, w, dx, **epi):
     return conv_gather(dy, w, dx, Cin, K, 2, Cout * K, K, **epi)
 
 
+def wq_relayout(w: Tensor, wq: Tensor, N: int, Cc: int, K: int, w_sn: int, w_sc: int) -> Tensor:
+    """wq[((c/4)*K + k)*N + n][c%4] = w[n*w_sn + c*w_sc + k]: the weight layout of conv16 (see mg_conv16)."""
+    _chk(w, "w")
+    _chk(wq, "wq")
+    if wq.numel() != N * Cc * K or w.numel() < (N - 1) * w_sn + (Cc - 1) * w_sc + K or Cc % 4:
+        raise ValueError("wq_relayout: size mismatch")
+    L.check(L.load().mg_wq_relayout(_p(w), _p(wq), N, Cc, K, w_sn, w_sc, _stream()), "mg_wq_relayout")
+    return wq
+
+
+def conv16_supported(B: int, Tin: int, Cin: int, N: int, transposed: bool, Tout: int = 0) -> bool:
+    return bool(L.load().mg_conv16_supported(B, Tin, Cin, N, 1 if transposed else 0, Tout))
+
+
+def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool = False, **epi) -> Tensor:
+    """Stride-2 K=5 window GEMM on 16x16 MFMA tiles with WQ-layout weights (mg_conv16).  transposed=False: the gather
+    form (Conv1d forward / ConvTranspose1d data-gradient), True: the scatter form (ConvTranspose1d forward / Conv1d
+    data-gradient; odd: Tout = 2*Tin - 1).  y: (B, Ty >= Tout, N)."""
+    _chk(x, "x")
+    _chk(wq, "wq")
+    _chk(y, "y")
+    B, Tin, Cin = x.shape
+    Tout = (2 * Tin - (1 if odd else 0)) if transposed else (Tin + 4 - 5) // 2 + 1
+    if y.dim() != 3 or y.shape[0] != B or y.shape[2] != N or y.shape[1] < Tout:
+        raise ValueError(f"y: expected (B={B}, >={Tout}, {N}), got {tuple(y.shape)}")
+    if wq.numel() != N * Cin * 5:
+        raise ValueError(f"wq: numel {wq.numel()} != {N * Cin * 5}")
+    e = epilogue((B, Tout, N), N, **epi)
+    if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
+        raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
+    lib = L.load()
+    if not lib.mg_conv16_supported(B, Tin, Cin, N, 1 if transposed else 0, Tout):
+        raise ValueError(f"conv16: unsupported shape B={B} Tin={Tin} Cin={Cin} N={N}")
+    def launch():
+        return lib.mg_conv16(_p(x), _p(wq), _p(y), B, Tin, Cin, N, 1 if transposed else 0, Tout, Tin * Cin, y.shape[1] * N,
+                             C.byref(e), _stream())
+    sym = lambda: "conv16_kernel<%s>" % ("true" if transposed else "false")  # noqa: E731
+    with _observe(sym, 2.0 * B * (Tin if transposed else Tout) * N * Cin * 5, launch):
+        rc = launch()
+    L.check(rc, "mg_conv16")
+    return y
+
+
 SKINNY_MAX_ROWS = 512      # Linear layers with at most this many rows use the skinny-GEMM kernel
 
 
@@ -746,8 +789,21 @@ def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_sta
                                  n(mask1), p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(step_counter), _stream()), "mg_rng_fill")
 
 
+def wq_table(entries):
+    """ctypes table for adam_flat(wq=...): entries = [(start, N, Cc, K, w_sn, w_sc, dst tensor), ...] (mg_wq_entry)."""
+    if len(entries) > L.MAX_WQ_ENTRIES:
+        raise ValueError(f"wq_table: at most {L.MAX_WQ_ENTRIES} entries")
+    arr = (L.WqEntry * max(1, len(entries)))()
+    for a, (start, N, Cc, K, sn, sc, dst) in zip(arr, entries):
+        _chk(dst, "wq dst")
+        if dst.numel() != N * Cc * K:
+            raise ValueError("wq_table: dst size mismatch")
+        a.start, a.N, a.Cc, a.K, a.w_sn, a.w_sc, a.dst = start, N, Cc, K, sn, sc, dst.data_ptr()
+    return arr, len(entries), [e[6] for e in entries]          # keeps the destinations alive
+
+
 def adam_flat(p, g, m, v, state, lr, beta1, beta2, eps=1e-8, weight_decay=0.0, grad_scale=1.0, gs_dev=None,
-              ticked_rng_step=None, ticked=False):
+              ticked_rng_step=None, ticked=False, wq=None):
     """Fused flat Adam/AdamW.  ticked_rng_step: `state` was already advanced by rng_fill(tick_state=state); apply the
     update only and advance that Philox step counter (one launch instead of two).  ticked=True without a counter: the
     state was advanced by the draw, and another update advances the counter (rng_fill(tick_state2=...))."""
@@ -757,6 +813,13 @@ def adam_flat(p, g, m, v, state, lr, beta1, beta2, eps=1e-8, weight_decay=0.0, g
         if t.numel() != n:
             raise ValueError("adam_flat: size mismatch")
     _chk(state, "state", (4,), torch.float64)
+    if wq is not None:             # the update also refreshes WQ-layout weight copies (wq_table)
+        if ticked_rng_step is not None:
+            _chk(ticked_rng_step, "ticked_rng_step", (1,), torch.int64)
+        L.check(L.load().mg_adam_flat_wq(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, _p(state),
+                                         grad_scale, _p(gs_dev), 1 if (ticked or ticked_rng_step is not None) else 0,
+                                         _p(ticked_rng_step), wq[0], wq[1], _stream()), "mg_adam_flat_wq")
+        return
     if ticked_rng_step is not None or ticked:
         if ticked_rng_step is not None:
             _chk(ticked_rng_step, "ticked_rng_step", (1,), torch.int64)

@@ -1,0 +1,103 @@
+"""conv16 (csrc/conv16_mfma.hip: the stride-2 five-tap window GEMMs on 16x16x4 MFMA tiles, WQ-layout weights) against a
+plain PyTorch fp32 reference of the same op, over the layer shapes of the critic / generator and ragged ones, with the
+fused epilogue's pieces; and bit-for-bit run-to-run reproducibility (no split-K, no atomics)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def wq_of(ops, w, N, Cc, sn, sc):
+    wq = torch.empty(N * Cc * 5, device="cuda")
+    ops.wq_relayout(w.cuda().contiguous(), wq, N, Cc, 5, sn, sc)
+    return wq
+
+
+def close(got, ref, tol=2e-5):
+    err = float((got.cpu().double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
+    assert err < tol, err
+
+
+# (B, T, Cin, Cout): critic conv.0 / conv.2 / conv.4 at B and 3B rows, plus ragged batch / odd lengths / short rolls
+CONV_SHAPES = [(64, 256, 128, 64), (64, 128, 64, 128), (64, 64, 128, 256), (192, 64, 128, 256), (3, 20, 32, 32),
+               (5, 33, 32, 64), (2, 8, 32, 32), (7, 100, 64, 96)]
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout", CONV_SHAPES)
+def test_conv_s2_forward_and_data_gradient(ops, B, T, Cin, Cout):
+    x, w, bias = rnd(B, T, Cin, seed=1), rnd(Cout, Cin, 5, seed=2, scale=0.05), rnd(Cout, seed=3)
+    Tout = (T - 1) // 2 + 1
+    ref = F.conv1d(x.transpose(1, 2), w, bias, stride=2, padding=2).transpose(1, 2)
+    assert ops.conv16_supported(B, T, Cin, Cout, False)
+    y = torch.full((B, Tout, Cout), float("nan"), device="cuda")
+    ops.conv16(x.cuda(), wq_of(ops, w, Cout, Cin, Cin * 5, 5), y, Cout, False, bias=bias.cuda())
+    close(y, ref)
+    # LeakyReLU + saved pre-activation, as the critic's forward uses it
+    z = torch.empty_like(y)
+    ops.conv16(x.cuda(), wq_of(ops, w, Cout, Cin, Cin * 5, 5), y, Cout, False, bias=bias.cuda(), zout=z, act=ops.ACT_LRELU)
+    close(z, ref)
+    close(y, F.leaky_relu(ref, 0.2))
+    # data gradient (the transposed form: n = Cin, c = Cout), times the LeakyReLU mask of a reference tensor
+    dy = rnd(B, Tout, Cout, seed=4)
+    xr = x.clone().requires_grad_(True)
+    F.conv1d(xr.transpose(1, 2), w, None, stride=2, padding=2).transpose(1, 2).backward(dy)
+    assert ops.conv16_supported(B, Tout, Cout, Cin, True, T)
+    dx = torch.full((B, T, Cin), float("nan"), device="cuda")
+    wq_d = wq_of(ops, w, Cin, Cout, 5, Cin * 5)
+    ops.conv16(dy.cuda(), wq_d, dx, Cin, True, odd=(T % 2 == 1))
+    close(dx, xr.grad)
+    gref = rnd(B, T, Cin, seed=5)
+    ops.conv16(dy.cuda(), wq_d, dx, Cin, True, odd=(T % 2 == 1), gref=gref.cuda(), gact=ops.ACT_LRELU)
+    close(dx, xr.grad * torch.where(gref > 0, 1.0, 0.2))
+    # accumulate into an existing gradient
+    base = rnd(B, T, Cin, seed=6)
+    dx.copy_(base)
+    ops.conv16(dy.cuda(), wq_d, dx, Cin, True, odd=(T % 2 == 1), accumulate=True)
+    close(dx, xr.grad + base)
+
+
+# (B, L, Cin, Cout): generator deconv.0 / .3 / .6 at B and 2B rows, ragged ones
+CONVT_SHAPES = [(64, 32, 256, 128), (128, 64, 128, 64), (128, 128, 64, 128), (3, 5, 16, 32), (4, 12, 32, 64)]
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout", CONVT_SHAPES)
+def test_convT_s2_forward_and_data_gradient(ops, B, L, Cin, Cout):
+    x, w, bias = rnd(B, L, Cin, seed=1), rnd(Cin, Cout, 5, seed=2, scale=0.05), rnd(Cout, seed=3)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv_transpose1d(xr.transpose(1, 2), w, bias, stride=2, padding=2, output_padding=1).transpose(1, 2)
+    y = torch.full((B, 2 * L, Cout), float("nan"), device="cuda")
+    ops.conv16(x.cuda(), wq_of(ops, w, Cout, Cin, 5, Cout * 5), y, Cout, True, bias=bias.cuda())
+    close(y, ref.detach())
+    y2 = torch.full((B, 2 * L, Cout), float("nan"), device="cuda")
+    ops.conv16(x.cuda(), wq_of(ops, w, Cout, Cin, 5, Cout * 5), y2, Cout, True, bias=bias.cuda())
+    assert torch.equal(y, y2)                                                   # run-to-run: identical bits
+    # zero-padded tail (the generator's T % 8 != 0 branch): rows beyond 2L stay untouched
+    ypad = torch.full((B, 2 * L + 3, Cout), 7.0, device="cuda")
+    ops.conv16(x.cuda(), wq_of(ops, w, Cout, Cin, 5, Cout * 5), ypad, Cout, True, bias=bias.cuda())
+    assert torch.equal(ypad[:, :2 * L], y) and bool((ypad[:, 2 * L:] == 7.0).all())
+    # data gradient (gather form: n = Cin, c = Cout)
+    dy = rnd(B, 2 * L, Cout, seed=4)
+    ref.backward(dy)
+    dx = torch.full((B, L, Cin), float("nan"), device="cuda")
+    ops.conv16(dy.cuda(), wq_of(ops, w, Cin, Cout, Cout * 5, 5), dx, Cin, False)
+    close(dx, xr.grad)
+
+
+def test_unsupported_shapes_are_refused(ops):
+    assert not ops.conv16_supported(4, 32, 4, 64, False)          # Cin % 16
+    assert not ops.conv16_supported(4, 32, 64, 4, False)          # N % 32
+    assert not ops.conv16_supported(4, 4, 64, 64, False)          # two output positions per roll
+    with pytest.raises(ValueError):
+        ops.conv16(torch.zeros(4, 32, 4, device="cuda"), torch.zeros(64 * 4 * 5, device="cuda"), torch.zeros(4, 16, 64, device="cuda"), 64, False)

@@ -144,6 +144,7 @@ def test_steps_match_oracle_and_golden(engine_mod, name):
         with torch.no_grad():
             for k, v in S.PD.items():
                 eng.D.p[k].copy_(v)
+            eng.params_changed()
         # ---- G-step ----
         eng.set_randoms(noise_g.cuda(), [m.cuda() for m in dm_g])
         eng.g_backward()
@@ -184,6 +185,7 @@ def test_steps_match_oracle_and_golden(engine_mod, name):
                 eng.GE.p[k].copy_(v)
             for k, v in S.BG.items():
                 eng.Gbuf[k].copy_(v)
+            eng.params_changed()
     assert eng.num_batches_tracked == S.bn_batches
     # eval-mode generation (app.py contract)
     z = O.closed_form((eng.B, cfg["NOISE_DIM"]), 11.0, 1.0)

@@ -73,6 +73,7 @@ def test_full_size_step_matches_oracle(setup):
     with torch.no_grad():
         for k, v in S.PD.items():
             eng.D.p[k].copy_(v)                          # teacher forcing (tests/test_engine_gpu.py)
+        eng.params_changed()
     eng.set_randoms(R["noise_g"].cuda(), [m.cuda() for m in R["dm_g"]])
     eng.g_backward()
     d64 = lambda P: type(P)((k, v.double().clone()) for k, v in P.items())  # noqa: E731
