@@ -87,111 +87,137 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     }
     const int bbase = xs_floats + kq * K5 * WPLANE + (16 * wn + li) * 4;
 
-    f32x4 acc[NPH][RT];
+    // RT = 1 leaves one accumulator per phase: consecutive MFMAs would wait 40 cycles for each other (the dependent
+    // latency of v_mfma_f32_16x16x4_f32) instead of issuing every 32, so the channel sum is kept in two accumulators
+    // (channels 4kq + {0,2} and 4kq + {1,3}) that the epilogue adds.
+    constexpr int KA = RT == 1 ? 2 : 1;
+    f32x4 acc[NPH][RT][KA];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[ph][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ka = 0; ka < KA; ++ka) acc[ph][rt][ka] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- staging plan: global -> registers (a chunk ahead) -> the other LDS buffer ----
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wq), 0, p.w_bytes, 0x00020000);
     const int sink = 2 * buf_floats + 4 * tid;      // per-thread 16-B sink for slots without data
-    unsigned xo[MAXX];
-    int xl[MAXX], xd[MAXX];
+    constexpr int NST = MAXX + NWU;                 // staging units per thread: window slots, then weight slots
+    unsigned so[NST];      // byte offset of the unit's float4 (without the chunk term)
+    int sl[NST], sd[NST];  // float offset inside buffer 0 (or the sink) and what to add for buffer 1 (0 for the sink)
 #pragma unroll
     for (int j = 0; j < MAXX; ++j) {
         const int idx = tid + 256 * j;
-        xo[j] = 0x80000000u;          // beyond num_records: the hardware returns 0
-        xl[j] = sink;
-        xd[j] = 0;
+        so[j] = 0x80000000u;          // beyond num_records: the hardware returns 0
+        sl[j] = sink;
+        sd[j] = 0;
         if (idx < nrows * 4) {
             const int row = idx >> 2, q = idx & 3;
             const int seg = (TB == 1) ? 0 : row / R, r = row - seg * R;
             const int b = b0 + seg, tin = tin0 + r;
-            xl[j] = row * SX + 4 * q;
-            xd[j] = buf_floats;
+            sl[j] = row * SX + 4 * q;
+            sd[j] = buf_floats;
             if (b < p.B && tin >= 0 && tin < p.Tin)
-                xo[j] = ((unsigned)b * (unsigned)p.xbs + (unsigned)(tin * p.Cin + 4 * q)) * 4u;
+                so[j] = ((unsigned)b * (unsigned)p.xbs + (unsigned)(tin * p.Cin + 4 * q)) * 4u;
         }
     }
-    unsigned wo[NWU];
-    int wl[NWU], wd[NWU];
 #pragma unroll
     for (int i = 0; i < NWU; ++i) {
         const int u = tid + 256 * i;
-        wo[i] = 0x80000000u;
-        wl[i] = sink;
-        wd[i] = 0;
+        so[MAXX + i] = 0x80000000u;
+        sl[MAXX + i] = sink;
+        sd[MAXX + i] = 0;
         if (u < 4 * K5 * BN) {
             const int pl = u >> 5, n = u & 31;
-            wl[i] = xs_floats + u * 4;
-            wd[i] = buf_floats;
-            if (n0 + n < p.N) wo[i] = ((unsigned)pl * (unsigned)p.N + (unsigned)(n0 + n)) * 16u;
+            sl[MAXX + i] = xs_floats + u * 4;
+            sd[MAXX + i] = buf_floats;
+            if (n0 + n < p.N) so[MAXX + i] = ((unsigned)pl * (unsigned)p.N + (unsigned)(n0 + n)) * 16u;
         }
     }
     const unsigned wchunk = (unsigned)(K5 * p.N) * 16u;     // bytes between consecutive channel quads' plane groups
-    f32x4 xr[MAXX], wr[NWU];
+    f32x4 sr[NST];
     auto bload = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned voff, unsigned soff) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
         return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
     };
-    auto load_chunk = [&](int c0) {
-        const unsigned xs = 4u * (unsigned)c0, ws = (unsigned)(c0 >> 2) * wchunk;
-#pragma unroll
-        for (int j = 0; j < MAXX; ++j) xr[j] = bload(xrsrc, xo[j], xs);
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) wr[i] = bload(wrsrc, wo[i], ws);
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < MAXX; ++j) *lds4(xl[j] + (buf ? xd[j] : 0)) = xr[j];
-#pragma unroll
-        for (int i = 0; i < NWU; ++i) *lds4(wl[i] + (buf ? wd[i] : 0)) = wr[i];
-    };
+    auto load_unit = [&](int u, unsigned xs, unsigned ws) { sr[u] = u < MAXX ? bload(xrsrc, so[u], xs) : bload(wrsrc, so[u], ws); };
+    auto store_unit = [&](int u, int buf) { *lds4(sl[u] + (buf ? sd[u] : 0)) = sr[u]; };
 
     // One chunk = 5 slots of 4*RT MFMAs: slot q pairs tap k with a window-row offset ro (and, transposed, a phase):
     //   gather     : (k, ro) = (q, q)
     //   transposed : phase 0 (t = 2u):   k = 0 <- row u+1, k = 2 <- row u, k = 4 <- row u-1
     //                phase 1 (t = 2u+1): k = 1 <- row u+1, k = 3 <- row u            (window row 0 is u-1)
-    auto slot_tap = [](int q) { return q; };
     auto slot_row = [](int q) { return TR2 ? (q < 2 ? 2 : (q < 4 ? 1 : 0)) : q; };
     auto slot_ph = [](int q) { return TR2 ? (q & 1) : 0; };
-    auto frag_read = [&](int boff, int q, f32x4 (&A)[RT], f32x4& Bv) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) A[rt] = *lds4(boff + abase[rt] + slot_row(q) * SX);
-        Bv = *lds4(boff + bbase + slot_tap(q) * WPLANE);
-    };
     f32x4 fa[2][RT], fb[2];
-    auto chunk = [&](auto parity, int c_next2, bool more) {
-        constexpr int P = decltype(parity)::value;
-        const int cur = P ? buf_floats : 0;
-        frag_read(cur, 0, fa[0], fb[0]);
-        if (more) store_chunk(1 - P);           // registers hold the next chunk: into the other buffer ...
-        load_chunk(c_next2);                    // ... and reload them with the chunk after that (clamped: harmless re-read)
+    // piece g of slot q's operands: g < RT -> the window rows of row tile g, g == RT -> the weight columns
+    auto frag_piece = [&](int boff, int q, int g, f32x4 (&A)[RT], f32x4& Bv) {
+        if (g < RT) A[g] = *lds4(boff + abase[g < RT ? g : 0] + slot_row(q) * SX);
+        else Bv = *lds4(boff + bbase + q * WPLANE);
+    };
+
+    // Gap-scheduled loop (conv_mfma.hip): a wave issues in order, so whatever is to hide under the
+    // matrix pipe sits in the gap right behind an MFMA, one memory instruction per gap (two where the gaps run out),
+    // pinned by sched_barrier; left to hipcc the prefetch loads shared registers with the operand reads and every
+    // ds_read waited for global memory.  Per chunk: GPS = 4*RT MFMAs per slot;
+    //   gaps 0..RT of slot q      the RT+1 operand reads of slot q+1 (other register set)
+    //   the remaining gaps of slots 0-3   the six staging units: registers (next chunk) -> other LDS buffer, then the
+    //                                     registers reloaded with the chunk after that -- all stores before all loads
+    //   slot 4                     gap 0: the chunk's barrier; gaps 1..RT+1: operand reads of the NEXT chunk's slot 0
+    // No branches: past the end the last chunk is re-staged into the idle buffer.
+    constexpr int GPS = 4 * RT, NSLOT = K5, NFR = RT + 1;
+    constexpr int FREE = GPS - NFR;
+    constexpr int NOPS = 2 * NST;
+    constexpr int OPG = (NOPS + 4 * FREE - 1) / (4 * FREE);
+    static_assert(NFR + 1 <= GPS && OPG * 4 * FREE >= NOPS, "gap plan");
+    auto chunk = [&](auto parity, int c_next2) {
+        constexpr int P = decltype(parity)::value;      // LDS buffer being read; also the operand register set of slot 0
+        const int cur = P ? buf_floats : 0, oth = buf_floats - cur;
+        const unsigned xs = 4u * (unsigned)c_next2, ws = (unsigned)(c_next2 >> 2) * wchunk;
 #pragma unroll
-        for (int q = 0; q < K5; ++q) {
-            if (q + 1 < K5) frag_read(cur, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
-            const int ph = slot_ph(q);
+        for (int m = 0; m < NSLOT * GPS; ++m) {
+            const int q = m / GPS, g = m % GPS;
+            const int s4 = g / RT, rt = g % RT, set = (q + P) & 1;
+            acc[slot_ph(q)][rt][s4 % KA] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[set][rt][s4], fb[set][s4],
+                                                                                 acc[slot_ph(q)][rt][s4 % KA], 0, 0, 0);
+            if (q + 1 < NSLOT) {
+                if (g < NFR) {
+                    frag_piece(cur, q + 1, g, fa[set ^ 1], fb[set ^ 1]);
+                } else {
+                    const int idx = q * FREE + (g - NFR);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[ph][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q & 1][rt][s], fb[q & 1][s], acc[ph][rt], 0, 0, 0);
+                    for (int o = idx * OPG; o < (idx + 1) * OPG && o < NOPS; ++o) {
+                        if (o < NST) store_unit(o, 1 - P);
+                        else load_unit(o - NST, xs, ws);
+                    }
+                }
+            } else {
+                if (g == 0) __syncthreads();            // the other buffer is complete, this one is read out
+                else if (g <= NFR) frag_piece(oth, 0, g - 1, fa[set ^ 1], fb[set ^ 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
     };
 
     const int c_last = p.Cin - BKC;
-    load_chunk(0);
-    store_chunk(0);
-    load_chunk(min(BKC, c_last));
-    __syncthreads();
+    {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) load_unit(u, 0u, 0u);
+#pragma unroll
+        for (int u = 0; u < NST; ++u) store_unit(u, 0);
+        const int c1 = min(BKC, c_last);
+#pragma unroll
+        for (int u = 0; u < NST; ++u) load_unit(u, 4u * (unsigned)c1, (unsigned)(c1 >> 2) * wchunk);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < NFR; ++g) frag_piece(0, 0, g, fa[0], fb[0]);
+    }
     for (int c0 = 0;;) {
-        chunk(std::integral_constant<int, 0>{}, min(c0 + 2 * BKC, c_last), c0 + BKC < p.Cin);
+        chunk(std::integral_constant<int, 0>{}, min(c0 + 2 * BKC, c_last));
         c0 += BKC;
         if (c0 >= p.Cin) break;
-        chunk(std::integral_constant<int, 1>{}, min(c0 + 2 * BKC, c_last), c0 + BKC < p.Cin);
+        chunk(std::integral_constant<int, 1>{}, min(c0 + 2 * BKC, c_last));
         c0 += BKC;
         if (c0 >= p.Cin) break;
     }
@@ -207,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            f32x4 a = acc[ph][rt];
+            f32x4 a = acc[ph][rt][0];
+            if constexpr (KA == 2) a += acc[ph][rt][1];
             unsigned di[4], yi[4];
             bool ok[4];
 #pragma unroll

@@ -334,9 +334,8 @@ class GanEngine:
 
     def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, **epi):
         """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
-        convT_fwd / convT_dgrad (nn.ConvTranspose1d, weight (Cin,Cout,5)).  conv16 (no split-K, no finish launch) where
-        it covers the shape -- always for the gather form, for the transposed form where the 64x64-tile kernel would
-        have to split the reduction (< 192 workgroups; above that the two are on par, tools/conv16_bench.py)."""
+        convT_fwd / convT_dgrad (nn.ConvTranspose1d, weight (Cin,Cout,5)).  conv16 (no split-K, no finish launch) wherever
+        it covers the shape (faster on every cfg2 layer, tools/conv16_bench.py); the 64x64-tile kernel otherwise."""
         w = fp.p[name]
         transposed = kind in ("conv_dgrad", "convT_fwd")
         direction = "fwd" if kind.endswith("fwd") else "dgrad"
@@ -345,8 +344,7 @@ class GanEngine:
         B, Tin, Cin = x.shape
         odd = transposed and y.shape[1] == 2 * Tin - 1 and kind == "conv_dgrad"
         if wq is not None and ops.conv16_supported(B, Tin, Cin, N, transposed, (2 * Tin - (1 if odd else 0)) if transposed else 0):
-            if not transposed or -(-B * Tin // 64) * -(-N // 64) < 192:
-                return ops.conv16(x, wq, y, N, transposed, odd=odd, **epi)
+            return ops.conv16(x, wq, y, N, transposed, odd=odd, **epi)
         if kind == "conv_fwd":
             return ops.conv1d_fwd(x, w, y, 2, **epi)
         if kind == "conv_dgrad":
