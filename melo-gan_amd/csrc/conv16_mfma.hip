@@ -37,6 +37,13 @@ struct Conv16P {
     int tt_log2, n_ttiles;
     unsigned nt_magic;
     mg_epilogue e;
+    // optional per-column statistics of the stored values v (BatchNorm fused into the producing convolution): every
+    // wave writes, for its 16 columns, part[(2*mtile + wm)][0][n] = sum v and [1][n] = sum v*v -- or, with xh_z,
+    // sum v * xhat, xhat = (xh_z - xh_mean[n]) * xh_invstd[n] (BatchNorm backward: v = dy) -- over its valid rows
+    float* part;
+    const float* xh_z;
+    const float* xh_mean;
+    const float* xh_invstd;
 };
 
 constexpr int K5 = 5;
@@ -229,6 +236,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     const float bias = E.bias ? E.bias[n] : 0.f;
     const float scale = E.scale ? E.scale[n] : 1.f, shift = E.scale ? E.shift[n] : 0.f;
     const float gscale = E.gscale ? E.gscale[n] : 1.f;
+    float st1 = 0.f, st2 = 0.f;
+    const float xh_mu = p.xh_z ? p.xh_mean[n] : 0.f, xh_is = p.xh_z ? p.xh_invstd[n] : 0.f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -293,6 +302,14 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] *= gscale;
+            if (p.part) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[r]) {
+                        st1 += a[r];
+                        st2 += a[r] * (p.xh_z ? (p.xh_z[di[r]] - xh_mu) * xh_is : a[r]);
+                    }
+            }
             if (E.accumulate) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -302,6 +319,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
             for (int r = 0; r < 4; ++r)
                 if (ok[r]) p.y[yi[r]] = a[r];
         }
+    if (p.part) {        // the four lanes of a column (row groups kq = 0..3) -> one partial per wave and column
+        st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
+        st2 += __shfl_xor(st2, 16, 64); st2 += __shfl_xor(st2, 32, 64);
+        if (kq == 0) {
+            float* dst = p.part + (long)(2 * blockIdx.x + wm) * 2 * p.N + n;
+            dst[0] = st1;
+            dst[p.N] = st2;
+        }
+    }
 }
 
 // wq[((c/4)*K + k)*N + n][c%4] = w[n*sn + c*sc + k]
@@ -381,9 +407,34 @@ extern "C" int mg_conv16_supported(int B, int Tin, int Cin, int N, int transpose
     return TB * R * 4 <= 256 * MAXX;
 }
 
+// The tiling mg_conv16 picks for a shape: batch rows per tile (a tile never straddles a multiple of it) and the number of
+// partial-statistics rows a launch with `part` writes (2 per workgroup column block: grid.x * 2).
+extern "C" int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows) {
+    const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
+    const int BM = 32 * pick_rt((long)B * Tm, N);
+    int lg = mg_ilog2_ceil(Tm);
+    if (lg > mg_ilog2_ceil(BM)) lg = mg_ilog2_ceil(BM);
+    const int TT = 1 << lg, TB = BM >> lg;
+    if (batch_rows_per_tile) *batch_rows_per_tile = TB;
+    if (part_rows) *part_rows = 2 * (int)(mg_cdiv(Tm, TT) * mg_cdiv(B, TB));
+    return MG_OK;
+}
+
+extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+                               long xbs, long ybs, const mg_epilogue* epi, float* part, const float* xh_z, const float* xh_mean,
+                               const float* xh_invstd, mg_stream_t stream);
+
 extern "C" int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                          long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream) {
+    return mg_conv16_stats(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+                               long xbs, long ybs, const mg_epilogue* epi, float* part, const float* xh_z, const float* xh_mean,
+                               const float* xh_invstd, mg_stream_t stream) {
     MG_CHECK_ARG(x && wq && y, "mg_conv16: null tensor");
+    MG_CHECK_ARG(!xh_z || (part && xh_mean && xh_invstd), "mg_conv16: xh_z needs part, xh_mean and xh_invstd");
+    MG_CHECK_ARG(!(part && epi && epi->accumulate), "mg_conv16: statistics of an accumulating launch are not defined");
     const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
     if (!transposed) Tout = Tm;
     MG_CHECK_ARG(mg_conv16_supported(B, Tin, Cin, N, transposed, Tout), "mg_conv16: unsupported shape B=%d Tin=%d Cin=%d N=%d", B, Tin, Cin, N);
@@ -400,6 +451,7 @@ extern "C" int mg_conv16(const float* x, const float* wq, float* y, int B, int T
         p.e = *epi;
         MG_CHECK_ARG(!(p.e.scale && !p.e.shift), "epilogue: scale without shift");
     }
+    p.part = part; p.xh_z = xh_z; p.xh_mean = xh_mean; p.xh_invstd = xh_invstd;
     hipStream_t s = (hipStream_t)stream;
     const int rt = pick_rt((long)B * Tm, N);
     int rc;
