@@ -107,27 +107,19 @@ int mg_wq_relayout(const float* w, float* wq, int N, int Cc, int K, int w_sn, in
 int mg_conv16_supported(int B, int Tin, int Cin, int N, int transposed, int Tout);
 int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
               long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream);
-/* The same launch that ALSO leaves per-column partial statistics of the values v it stores, so that the BatchNorm that
- * follows (forward) or that this data-gradient feeds (backward) needs no reduction pass of its own:
- *   part[(2*tile + wave_row)][0][n] = sum_rows v[row, n],   [1][n] = sum v*v          (xh_z == NULL; BatchNorm forward, v = z)
- *                                                            [1][n] = sum v*xhat,  xhat = (xh_z - xh_mean[n]) * xh_invstd[n]
- *                                                                                       (BatchNorm backward, v = dy)
- * part: 2 * part_rows * N floats, part_rows and the batch rows a tile spans from mg_conv16_plan (a caller that stacks
+/* The same launch that ALSO leaves per-column partial statistics of the values v it stores, so that the train-mode
+ * BatchNorm that follows needs no reduction pass of its own:
+ *   part[(2*tile + wave_row)][0][n] = sum_rows v[row, n],   [1][n] = sum v*v
+ * part: 2 * part_rows * N floats; part_rows and the batch rows a tile spans from mg_conv16_plan (a caller that stacks
  * several BatchNorm groups along the batch needs the group size to be a multiple of batch_rows_per_tile).
- * mg_bn_train_fwd_parts / mg_bn_train_bwd_parts finish the statistics (fixed order, fp64) and apply them in ONE launch
- * each (nn.BatchNorm1d training forward / backward, src/gan/models.py:57-61): fwd as mg_bn_train_fwd_groups, bwd:
- * dz = gamma*invstd*(dy - sum(dy)/R - xhat*sum(dy*xhat)/R), dgamma = sum(dy*xhat), dbeta = sum(dy), dy = the tensor the
- * producing launch stored (da times the activation derivative, via its epilogue's gref/gact). */
+ * mg_bn_train_fwd_parts finishes the statistics (fixed order, fp64), moves the running ones and applies: the semantics of
+ * mg_bn_train_fwd_groups (nn.BatchNorm1d training forward, src/gan/models.py:57-61) in two launches instead of three. */
 int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows);
 int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
-                    long xbs, long ybs, const mg_epilogue* epi, float* part, const float* xh_z, const float* xh_mean,
-                    const float* xh_invstd, mg_stream_t stream);
+                    long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream);
 int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups, const float* z, float* a, long R, int C,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                           float eps, float* save_mean, float* save_invstd, int act, mg_stream_t stream);
-int mg_bn_train_bwd_parts(const float* part, int part_rows, const float* dy, const float* z, float* dz, long R, int C,
-                          const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                          mg_stream_t stream);
 
 /* ---- skinny GEMM for nn.Linear forward / data-gradient with few rows (M = batch) ----
  *   y[M,N] = EPI( x[M,K] @ W^T ),  W(n,c) = w[n*w_sn + c*w_sc], one of the strides must be 1:

@@ -37,13 +37,9 @@ struct Conv16P {
     int tt_log2, n_ttiles;
     unsigned nt_magic;
     mg_epilogue e;
-    // optional per-column statistics of the stored values v (BatchNorm fused into the producing convolution): every
-    // wave writes, for its 16 columns, part[(2*mtile + wm)][0][n] = sum v and [1][n] = sum v*v -- or, with xh_z,
-    // sum v * xhat, xhat = (xh_z - xh_mean[n]) * xh_invstd[n] (BatchNorm backward: v = dy) -- over its valid rows
+    // optional per-column statistics of the stored values v (the BatchNorm that follows needs no reduction pass): every
+    // wave writes, for its 16 columns, part[(2*mtile + wm)][0][n] = sum v and [1][n] = sum v*v over its valid rows
     float* part;
-    const float* xh_z;
-    const float* xh_mean;
-    const float* xh_invstd;
 };
 
 constexpr int K5 = 5;
@@ -237,7 +233,6 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     const float scale = E.scale ? E.scale[n] : 1.f, shift = E.scale ? E.shift[n] : 0.f;
     const float gscale = E.gscale ? E.gscale[n] : 1.f;
     float st1 = 0.f, st2 = 0.f;
-    const float xh_mu = p.xh_z ? p.xh_mean[n] : 0.f, xh_is = p.xh_z ? p.xh_invstd[n] : 0.f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -307,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
                 for (int r = 0; r < 4; ++r)
                     if (ok[r]) {
                         st1 += a[r];
-                        st2 += a[r] * (p.xh_z ? (p.xh_z[di[r]] - xh_mu) * xh_is : a[r]);
+                        st2 += a[r] * a[r];
                     }
             }
             if (E.accumulate) {
@@ -421,19 +416,16 @@ extern "C" int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_
 }
 
 extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
-                               long xbs, long ybs, const mg_epilogue* epi, float* part, const float* xh_z, const float* xh_mean,
-                               const float* xh_invstd, mg_stream_t stream);
+                               long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream);
 
 extern "C" int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                          long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream) {
-    return mg_conv16_stats(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, nullptr, nullptr, nullptr, nullptr, stream);
+    return mg_conv16_stats(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, nullptr, stream);
 }
 
 extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
-                               long xbs, long ybs, const mg_epilogue* epi, float* part, const float* xh_z, const float* xh_mean,
-                               const float* xh_invstd, mg_stream_t stream) {
+                               long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream) {
     MG_CHECK_ARG(x && wq && y, "mg_conv16: null tensor");
-    MG_CHECK_ARG(!xh_z || (part && xh_mean && xh_invstd), "mg_conv16: xh_z needs part, xh_mean and xh_invstd");
     MG_CHECK_ARG(!(part && epi && epi->accumulate), "mg_conv16: statistics of an accumulating launch are not defined");
     const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
     if (!transposed) Tout = Tm;
@@ -451,7 +443,7 @@ extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B,
         p.e = *epi;
         MG_CHECK_ARG(!(p.e.scale && !p.e.shift), "epilogue: scale without shift");
     }
-    p.part = part; p.xh_z = xh_z; p.xh_mean = xh_mean; p.xh_invstd = xh_invstd;
+    p.part = part;
     hipStream_t s = (hipStream_t)stream;
     const int rt = pick_rt((long)B * Tm, N);
     int rc;

@@ -253,11 +253,24 @@ __device__ __forceinline__ void reduce_parts64(const float* __restrict__ part, i
                                                double& s1, double& s2) {
     const int cx = threadIdx.x & 63, pl = threadIdx.x >> 6;      // 4 partial lanes per channel
     double a = 0.0, b = 0.0;
-    if (c0 + cx < C)
-        for (int q = pl; q < np; q += 4) {
-            a += (double)part[((long)q * 2) * C + c0 + cx];
-            b += (double)part[((long)q * 2 + 1) * C + c0 + cx];
+    if (c0 + cx < C) {
+        // eight independent load pairs in flight per round (a plain loop waits for every round trip in turn)
+        for (int q0 = pl; q0 < np; q0 += 32) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // always load (clamped row), select afterwards: a load behind a runtime condition makes hipcc branch
+                // around it and wait for each one in turn
+                const int q = q0 + 4 * j;
+                const long o = ((long)(q < np ? q : np - 1) * 2) * C + c0 + cx;
+                va[j] = part[o];
+                vb[j] = part[o + C];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (q0 + 4 * j < np) { a += (double)va[j]; b += (double)vb[j]; }
         }
+    }
     __syncthreads();
     sh[pl][cx] = a;
     sh[4 + pl][cx] = b;
@@ -266,124 +279,28 @@ __device__ __forceinline__ void reduce_parts64(const float* __restrict__ part, i
     s2 = sh[4][cx] + sh[5][cx] + sh[6][cx] + sh[7][cx];
 }
 
-__global__ __launch_bounds__(256) void bn_fwd_parts_kernel(const float* __restrict__ part, int np, int groups, long R, int C,
-                                                           long rows_per, const float* __restrict__ z, float* __restrict__ a,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* running_mean, float* running_var, float momentum, float eps,
-                                                           float* save_mean, float* save_invstd, int act) {
+// Final stage for statistics that arrive as conv16 partials: one block per 64 channels, every group in turn (fixed order,
+// fp64): batch mean / invstd per group, running statistics moved group after group.  The apply pass is bn_apply_kernel.
+__global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __restrict__ part, int np, int groups, long R, int C,
+                                                             float momentum, float eps, float* running_mean,
+                                                             float* running_var, float* save_mean, float* save_invstd) {
     __shared__ double sh[8][64];
-    __shared__ float st[2][64];
     const int c0 = blockIdx.x * 64, cx = threadIdx.x & 63;
-    const long slices_per_group = (R + rows_per - 1) / rows_per;
-    const int g = (int)(blockIdx.y / slices_per_group);
-    const long r0 = (blockIdx.y % slices_per_group) * rows_per;
-    if (blockIdx.y == 0) {
-        for (int gg = 0; gg < groups; ++gg) {
-            double s1, s2;
-            reduce_parts64(part + (long)gg * np * 2 * C, np, C, c0, sh, s1, s2);
-            if (threadIdx.x < 64 && c0 + cx < C) {
-                const double mean = s1 / (double)R;
-                double var = s2 / (double)R - mean * mean;
-                if (var < 0.0) var = 0.0;
-                save_mean[(long)gg * C + c0 + cx] = (float)mean;
-                save_invstd[(long)gg * C + c0 + cx] = (float)(1.0 / sqrt(var + (double)eps));
-                if (running_mean) {
-                    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-                    running_mean[c0 + cx] = (float)((1.0 - momentum) * running_mean[c0 + cx] + momentum * mean);
-                    running_var[c0 + cx] = (float)((1.0 - momentum) * running_var[c0 + cx] + momentum * unb);
-                }
+    for (int g = 0; g < groups; ++g) {
+        double s1, s2;
+        reduce_parts64(part + (long)g * np * 2 * C, np, C, c0, sh, s1, s2);
+        if (threadIdx.x < 64 && c0 + cx < C) {
+            const double mean = s1 / (double)R;
+            double var = s2 / (double)R - mean * mean;
+            if (var < 0.0) var = 0.0;
+            save_mean[(long)g * C + c0 + cx] = (float)mean;
+            save_invstd[(long)g * C + c0 + cx] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+                running_mean[c0 + cx] = (float)((1.0 - momentum) * running_mean[c0 + cx] + momentum * mean);
+                running_var[c0 + cx] = (float)((1.0 - momentum) * running_var[c0 + cx] + momentum * unb);
             }
         }
-    }
-    double s1, s2;
-    reduce_parts64(part + (long)g * np * 2 * C, np, C, c0, sh, s1, s2);
-    if (threadIdx.x < 64) {
-        const double mean = s1 / (double)R;
-        double var = s2 / (double)R - mean * mean;
-        if (var < 0.0) var = 0.0;
-        st[0][cx] = (float)mean;
-        st[1][cx] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int c = c0 + 4 * cq;
-    if (c >= C) return;
-    long r1 = r0 + rows_per;
-    if (r1 > R) r1 = R;
-    const bool vec = ((C & 3) == 0) && (c + 3 < C);
-    float mu[4], is[4], ga[4], be[4];
-    for (int e = 0; e < 4; ++e) {
-        mu[e] = st[0][4 * cq + e]; is[e] = st[1][4 * cq + e];
-        ga[e] = c + e < C ? gamma[c + e] : 0.f; be[e] = c + e < C ? beta[c + e] : 0.f;
-    }
-    for (long r = r0 + ry; r < r1; r += 16) {
-        const long i = ((long)g * R + r) * C + c;
-        float v[4] = {0, 0, 0, 0};
-        if (vec) {
-            const float4 t = *reinterpret_cast<const float4*>(z + i);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else {
-            for (int e = 0; e < 4; ++e) if (c + e < C) v[e] = z[i + e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            v[e] = mg_act(act, (float)(((double)v[e] - (double)mu[e]) * (double)is[e] * (double)ga[e] + (double)be[e]));
-        if (vec) *reinterpret_cast<float4*>(a + i) = make_float4(v[0], v[1], v[2], v[3]);
-        else for (int e = 0; e < 4; ++e) if (c + e < C) a[i + e] = v[e];
-    }
-}
-
-// dz = gamma * invstd * (dy - sum(dy)/R - xhat * sum(dy*xhat)/R);  dgamma = sum(dy*xhat), dbeta = sum(dy)
-__global__ __launch_bounds__(256) void bn_bwd_parts_kernel(const float* __restrict__ part, int np, long R, int C, long rows_per,
-                                                           const float* __restrict__ dy, const float* __restrict__ z,
-                                                           float* __restrict__ dz, const float* __restrict__ gamma,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           float* dgamma, float* dbeta) {
-    __shared__ double sh[8][64];
-    __shared__ double st[2][64];
-    const int c0 = blockIdx.x * 64, cx = threadIdx.x & 63;
-    double s1, s2;
-    reduce_parts64(part, np, C, c0, sh, s1, s2);
-    if (threadIdx.x < 64) {
-        st[0][cx] = s1;
-        st[1][cx] = s2;
-        if (blockIdx.y == 0 && c0 + cx < C) {
-            dbeta[c0 + cx] = (float)s1;
-            dgamma[c0 + cx] = (float)s2;
-        }
-    }
-    __syncthreads();
-    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
-    const int c = c0 + 4 * cq;
-    if (c >= C) return;
-    const long r0 = (long)blockIdx.y * rows_per;
-    long r1 = r0 + rows_per;
-    if (r1 > R) r1 = R;
-    const bool vec = ((C & 3) == 0) && (c + 3 < C);
-    const double invR = 1.0 / (double)R;
-    double mu[4], is[4], ga[4], a1[4], a2[4];
-    for (int e = 0; e < 4; ++e) {
-        const bool in = c + e < C;
-        mu[e] = in ? (double)mean[c + e] : 0.0; is[e] = in ? (double)invstd[c + e] : 0.0; ga[e] = in ? (double)gamma[c + e] : 0.0;
-        a1[e] = st[0][4 * cq + e] * invR; a2[e] = st[1][4 * cq + e] * invR;
-    }
-    for (long r = r0 + ry; r < r1; r += 16) {
-        const long i = r * C + c;
-        float d[4] = {0, 0, 0, 0}, zz[4] = {0, 0, 0, 0};
-        if (vec) {
-            const float4 t = *reinterpret_cast<const float4*>(dy + i), u = *reinterpret_cast<const float4*>(z + i);
-            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; zz[0] = u.x; zz[1] = u.y; zz[2] = u.z; zz[3] = u.w;
-        } else {
-            for (int e = 0; e < 4; ++e) if (c + e < C) { d[e] = dy[i + e]; zz[e] = z[i + e]; }
-        }
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double xh = ((double)zz[e] - mu[e]) * is[e];
-            o[e] = (float)(ga[e] * is[e] * ((double)d[e] - a1[e] - xh * a2[e]));
-        }
-        if (vec) *reinterpret_cast<float4*>(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
-        else for (int e = 0; e < 4; ++e) if (c + e < C) dz[i + e] = o[e];
     }
 }
 
@@ -1049,40 +966,17 @@ int mg_bn_train_fwd(const float* z, float* a, long R, int C, const float* gamma,
                                   save_invstd, act, work, work_bytes, stream);
 }
 
-// rows per slice of the partial-statistics BatchNorm kernels: ~256 blocks over the tensor, slices never straddle a group
-static long bn_parts_rows_per(long R, int groups, int C) {
-    const long cb = mg_cdiv(C, 64);
-    long slices = mg_cdiv(256, cb * groups);
-    if (slices < 1) slices = 1;
-    long rp = mg_cdiv(R, slices);
-    if (rp < 16) rp = 16;
-    return rp;
-}
-
 int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups, const float* z, float* a, long R, int C,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                           float eps, float* save_mean, float* save_invstd, int act, mg_stream_t stream) {
     MG_CHECK_ARG(part && z && a && gamma && beta && save_mean && save_invstd && R > 0 && C > 0 && groups >= 1 &&
                  part_rows_per_group > 0, "mg_bn_train_fwd_parts: bad args");
     MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "mg_bn_train_fwd_parts: running stats must come in pairs");
-    const long rp = bn_parts_rows_per(R, groups, C);
-    dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)(mg_cdiv(R, rp) * groups));
-    hipLaunchKernelGGL(bn_fwd_parts_kernel, grid, dim3(256), 0, ST, part, part_rows_per_group, groups, R, C, rp, z, a, gamma, beta,
-                       running_mean, running_var, momentum, eps, save_mean, save_invstd, act);
+    hipLaunchKernelGGL(bn_parts_final_kernel, dim3((unsigned)mg_cdiv(C, 64)), dim3(256), 0, ST, part, part_rows_per_group, groups,
+                       R, C, momentum, eps, running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C * groups)), dim3(256), 0, ST, z, a, R * C * groups, C, gamma, beta,
+                       (const float*)save_mean, (const float*)save_invstd, act, R * C);
     MG_CHECK_LAUNCH("bn_train_fwd_parts");
-    return MG_OK;
-}
-
-int mg_bn_train_bwd_parts(const float* part, int part_rows, const float* dy, const float* z, float* dz, long R, int C,
-                          const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                          mg_stream_t stream) {
-    MG_CHECK_ARG(part && dy && z && dz && gamma && save_mean && save_invstd && dgamma && dbeta && R > 0 && C > 0 && part_rows > 0,
-                 "mg_bn_train_bwd_parts: bad args");
-    const long rp = bn_parts_rows_per(R, 1, C);
-    dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)mg_cdiv(R, rp));
-    hipLaunchKernelGGL(bn_bwd_parts_kernel, grid, dim3(256), 0, ST, part, part_rows, R, C, rp, dy, z, dz, gamma, save_mean,
-                       save_invstd, dgamma, dbeta);
-    MG_CHECK_LAUNCH("bn_train_bwd_parts");
     return MG_OK;
 }
 

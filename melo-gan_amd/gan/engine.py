@@ -336,8 +336,8 @@ class GanEngine:
         """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
         convT_fwd / convT_dgrad (nn.ConvTranspose1d, weight (Cin,Cout,5)).  conv16 (no split-K, no finish launch) wherever
         it covers the shape (faster on every cfg2 layer, tools/conv16_bench.py); the 64x64-tile kernel otherwise.
-        stats = dict(group_rows=..., xh=None | (z, mean, invstd)): ask the launch for per-column partial statistics of
-        what it stores (the BatchNorm around it then needs no reduction pass).  Returns (part, part_rows) if it did."""
+        stats = rows per BatchNorm group: ask the launch for per-column partial statistics of what it stores (the
+        BatchNorm that follows then needs no reduction pass).  Returns (part, part_rows) if it did, else None."""
         w = fp.p[name]
         transposed = kind in ("conv_dgrad", "convT_fwd")
         direction = "fwd" if kind.endswith("fwd") else "dgrad"
@@ -348,23 +348,21 @@ class GanEngine:
         if wq is not None and ops.conv16_supported(B, Tin, Cin, N, transposed, (2 * Tin - (1 if odd else 0)) if transposed else 0):
             if stats is not None:
                 tb, rows = ops.conv16_plan(B, Tin, N, transposed)
-                if stats["group_rows"] % tb == 0 and y.shape[1] == ((2 * Tin - (1 if odd else 0)) if transposed else (Tin - 1) // 2 + 1):
+                if stats % tb == 0:                 # no tile straddles two groups
                     part = ops.workspace(8 * rows * N, x.device, "bn_part").view(torch.float32)
-                    ops.conv16(x, wq, y, N, transposed, odd=odd, stats=(part,) + tuple(stats.get("xh") or (None, None, None)), **epi)
+                    ops.conv16(x, wq, y, N, transposed, odd=odd, stats=part, **epi)
                     return part, rows
-                if stats.get("xh") is not None:
-                    return None         # the caller launches without the activation derivative and takes the unfused path
             ops.conv16(x, wq, y, N, transposed, odd=odd, **epi)
             return None
-        if stats is not None and stats.get("xh") is not None:
-            return None
         if kind == "conv_fwd":
-            return ops.conv1d_fwd(x, w, y, 2, **epi)
-        if kind == "conv_dgrad":
-            return ops.conv1d_dgrad(x, w, y, 2, **epi)
-        if kind == "convT_fwd":
-            return ops.convT1d_fwd(x, w, y, **epi)
-        return ops.convT1d_dgrad(x, w, y, **epi)
+            ops.conv1d_fwd(x, w, y, 2, **epi)
+        elif kind == "conv_dgrad":
+            ops.conv1d_dgrad(x, w, y, 2, **epi)
+        elif kind == "convT_fwd":
+            ops.convT1d_fwd(x, w, y, **epi)
+        else:
+            ops.convT1d_dgrad(x, w, y, **epi)
+        return None
 
     # -------------------------------------------------------------------------------------
     # state in / out
@@ -531,7 +529,7 @@ class GanEngine:
         ops.linear_fwd(v("lat"), P("decoder.pre.0.weight"), v("a_p0"), bias=P("decoder.pre.0.bias"), act=ACT_RELU)
         ops.linear_fwd(v("a_p0"), P("decoder.pre.2.weight"), v("a_p2"), bias=P("decoder.pre.2.bias"), act=ACT_RELU)
         ops.transpose_bcl_blc(v("a_p2").view(n, 256, self.red), v("y0"))
-        st = dict(group_rows=self.B) if train else None
+        st = self.B if train else None
         pr = self._conv5s2("convT_fwd", v("y0"), self.GE, "G.decoder.deconv.0.weight", v("z_d0"), stats=st, bias=P("decoder.deconv.0.bias"))
         self._bn(v("z_d0"), v("a_d0"), "decoder.deconv.1", 0, train, which, pr)
         pr = self._conv5s2("convT_fwd", v("a_d0"), self.GE, "G.decoder.deconv.3.weight", v("z_d3"), stats=st, bias=P("decoder.deconv.3.bias"))
@@ -541,7 +539,7 @@ class GanEngine:
             self.num_batches_tracked += n // self.B
 
     def _bn(self, z, a, name, i, train, which="g", parts=None):
-        """parts: (partial statistics, rows) left by the producing conv16 launch -> one launch instead of three."""
+        """parts: (partial statistics, rows) left by the producing conv16 launch: no reduction pass over z."""
         P = self._gp
         if train:
             groups = 2 if which == "both" else 1
@@ -804,20 +802,14 @@ class GanEngine:
         if self.dn_dense is not None:      # zero-padded tail rows carry no gradient (models.py:78-81)
             ops.copy_cols(self.dnotes.view(B, -1), 0, self.dn_dense.view(B, -1), 0, self.L3 * self.C)
             dn = self.dn_dense
-        # each data gradient feeds a train-mode BatchNorm's backward: the conv16 launch applies ReLU' and leaves the two
-        # column sums BatchNorm backward needs (sum dy, sum dy * xhat), so that backward is one launch, not three
-        for dy_in, wname, da, a, z, dz, bn, i in (
-                (dn, "G.decoder.deconv.6.weight", self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, "decoder.deconv.4", 1),
-                (self.d_zd3, "G.decoder.deconv.3.weight", self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, "decoder.deconv.1", 0)):
-            pr = self._conv5s2("convT_dgrad", dy_in, self.GE, wname, da, gref=a, gact=ACT_RELU,
-                               stats=dict(group_rows=B, xh=(z, self.bn_mean[i], self.bn_invstd[i])))
-            if pr is not None:
-                ops.bn_train_bwd_parts(pr[0], pr[1], da, z, dz, PG(bn + ".weight"), self.bn_mean[i], self.bn_invstd[i],
-                                       GG(bn + ".weight"), GG(bn + ".bias"))
-            else:
-                self._conv5s2("convT_dgrad", dy_in, self.GE, wname, da)
-                ops.bn_train_bwd(da, a, z, dz, PG(bn + ".weight"), self.bn_mean[i], self.bn_invstd[i],
-                                 GG(bn + ".weight"), GG(bn + ".bias"), ACT_RELU)
+        self._conv5s2("convT_dgrad", dn, self.GE, "G.decoder.deconv.6.weight", self.d_ad3)
+        ops.bn_train_bwd(self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, PG("decoder.deconv.4.weight"), self.bn_mean[1],
+                         self.bn_invstd[1], GG("decoder.deconv.4.weight"), GG("decoder.deconv.4.bias"), ACT_RELU)
+        self._conv5s2("convT_dgrad", self.d_zd3, self.GE, "G.decoder.deconv.3.weight", self.d_ad0)
+        ops.bn_train_bwd(self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, PG("decoder.deconv.1.weight"), self.bn_mean[0],
+                         self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
+        # (Leaving BatchNorm backward's two column sums to the producing conv16 launch as well was built and measured:
+        #  its epilogue then reads a and z, scattered and exposed at the kernel's tail -- no faster than the reduction pass.)
         self._conv5s2("convT_dgrad", self.d_zd0, self.GE, "G.decoder.deconv.0.weight", self.d_y0)
         # (B, red, 256) -> reference (B, 256*red) order, times relu'
         ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red), gref=self.a_p2, gact=ACT_RELU)

@@ -219,8 +219,8 @@ def conv16_plan(B: int, Tin: int, N: int, transposed: bool):
 def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool = False, stats=None, **epi) -> Tensor:
     """Stride-2 K=5 window GEMM on 16x16 MFMA tiles with WQ-layout weights (mg_conv16).  transposed=False: the gather
     form (Conv1d forward / ConvTranspose1d data-gradient), True: the scatter form (ConvTranspose1d forward / Conv1d
-    data-gradient; odd: Tout = 2*Tin - 1).  y: (B, Ty >= Tout, N).  stats = (part, xh_z, xh_mean, xh_invstd): also write
-    per-column partial statistics of the stored values into `part` (mg_conv16_stats; the xh_* may be None)."""
+    data-gradient; odd: Tout = 2*Tin - 1).  y: (B, Ty >= Tout, N).  stats: a float buffer that receives per-column partial
+    statistics (sum, sum of squares) of the stored values (mg_conv16_stats; size from conv16_plan)."""
     _chk(x, "x")
     _chk(wq, "wq")
     _chk(y, "y")
@@ -236,22 +236,15 @@ def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool
     lib = L.load()
     if not lib.mg_conv16_supported(B, Tin, Cin, N, 1 if transposed else 0, Tout):
         raise ValueError(f"conv16: unsupported shape B={B} Tin={Tin} Cin={Cin} N={N}")
-    part = xz = xm = xi = None
+    part = None
     if stats is not None:
-        part, xz, xm, xi = stats
-        _chk(part, "part")
+        part = _chk(stats, "stats")
         if part.numel() < 2 * conv16_plan(B, Tin, N, transposed)[1] * N:
             raise ValueError("conv16: partial-statistics buffer too small (conv16_plan)")
-        if xz is not None:
-            _chk(xz, "xh_z")
-            _chk(xm, "xh_mean", (N,))
-            _chk(xi, "xh_invstd", (N,))
-            if xz.numel() != B * Tout * N or y.shape[1] != Tout:
-                raise ValueError("conv16: xh_z must have the output's dense shape")
 
     def launch():
         return lib.mg_conv16_stats(_p(x), _p(wq), _p(y), B, Tin, Cin, N, 1 if transposed else 0, Tout, Tin * Cin,
-                                   y.shape[1] * N, C.byref(e), _p(part), _p(xz), _p(xm), _p(xi), _stream())
+                                   y.shape[1] * N, C.byref(e), _p(part), _stream())
     sym = lambda: "conv16_kernel<%s>" % ("true" if transposed else "false")  # noqa: E731
     with _observe(sym, 2.0 * B * (Tin if transposed else Tout) * N * Cin * 5, launch):
         rc = launch()
@@ -501,7 +494,7 @@ def bn_train_fwd(z, a, gamma, beta, running_mean, running_var, save_mean, save_i
 def bn_train_fwd_parts(part, part_rows, groups, z, a, gamma, beta, running_mean, running_var, save_mean, save_invstd,
                        act=ACT_RELU, momentum=0.1, eps=1e-5):
     """bn_train_fwd from the partial column statistics the producing conv16 launch left in `part` (part_rows rows in
-    all, part_rows / groups per group): ONE launch -- finish the statistics, move the running ones, apply."""
+    all, part_rows / groups per group): finish the statistics and move the running ones (one small launch), apply."""
     _chk(z, "z")
     _chk(a, "a", z.shape)
     _chk(part, "part")
@@ -520,24 +513,6 @@ def bn_train_fwd_parts(part, part_rows, groups, z, a, gamma, beta, running_mean,
                                            _p(beta), _p(running_mean), _p(running_var), momentum, eps, _p(save_mean),
                                            _p(save_invstd), act, _stream()), "mg_bn_train_fwd_parts")
     return a
-
-
-def bn_train_bwd_parts(part, part_rows, dy, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta):
-    """BatchNorm backward from the partial sums (sum dy, sum dy*xhat) the producing conv16 launch left in `part`; dy
-    already carries the activation derivative.  ONE launch: dz, dgamma, dbeta."""
-    _chk(dy, "dy", z.shape)
-    _chk(z, "z")
-    _chk(dz, "dz", z.shape)
-    _chk(part, "part")
-    Cc = z.shape[-1]
-    if part.numel() < 2 * part_rows * Cc:
-        raise ValueError("bn_train_bwd_parts: partial buffer too small")
-    for nm, v in (("gamma", gamma), ("save_mean", save_mean), ("save_invstd", save_invstd), ("dgamma", dgamma), ("dbeta", dbeta)):
-        _chk(v, nm, (Cc,))
-    L.check(L.load().mg_bn_train_bwd_parts(_p(part), part_rows, _p(dy), _p(z), _p(dz), z.numel() // Cc, Cc, _p(gamma),
-                                           _p(save_mean), _p(save_invstd), _p(dgamma), _p(dbeta), _stream()),
-            "mg_bn_train_bwd_parts")
-    return dz
 
 
 def bn_train_bwd(da, a, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta, act=ACT_RELU, beta=None):

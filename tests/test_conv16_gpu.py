@@ -103,10 +103,10 @@ def test_unsupported_shapes_are_refused(ops):
         ops.conv16(torch.zeros(4, 32, 4, device="cuda"), torch.zeros(64 * 4 * 5, device="cuda"), torch.zeros(4, 16, 64, device="cuda"), 64, False)
 
 
-@pytest.mark.parametrize("B,L,Cin,Cout,groups", [(128, 32, 256, 128, 2), (64, 64, 128, 64, 1), (6, 12, 32, 64, 2)])
+@pytest.mark.parametrize("B,L,Cin,Cout,groups", [(128, 32, 256, 128, 2), (64, 64, 128, 64, 1), (8, 12, 32, 64, 2)])
 def test_batchnorm_from_the_convolutions_partial_statistics(ops, B, L, Cin, Cout, groups):
-    """conv16 leaves per-column partial sums of what it stores; BatchNorm forward / backward finish them in one launch
-    each.  Against the stand-alone three-launch BatchNorm kernels (themselves pinned to the reference in
+    """conv16 leaves per-column partial sums of what it stores; BatchNorm forward finishes them without a reduction pass
+    over the tensor.  Against the stand-alone three-launch BatchNorm kernels (themselves pinned to the reference in
     test_kernels_gpu.py / test_engine_gpu.py) and against torch's batch_norm."""
     x, w, bias = rnd(B, L, Cin, seed=1), rnd(Cin, Cout, 5, seed=2, scale=0.05), rnd(Cout, seed=3)
     gamma, beta = rnd(Cout, seed=4).abs() + 0.5, rnd(Cout, seed=5)
@@ -115,7 +115,7 @@ def test_batchnorm_from_the_convolutions_partial_statistics(ops, B, L, Cin, Cout
     assert (B // groups) % tb == 0
     part = torch.full((2 * rows * Cout,), float("nan"), device="cuda")
     z = torch.empty(B, 2 * L, Cout, device="cuda")
-    ops.conv16(x.cuda(), wq, z, Cout, True, bias=bias.cuda(), stats=(part, None, None, None))
+    ops.conv16(x.cuda(), wq, z, Cout, True, bias=bias.cuda(), stats=part)
     a1, a2 = torch.empty_like(z), torch.empty_like(z)
     rm1, rv1, rm2, rv2 = (torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda"),
                           torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda"))
@@ -128,22 +128,3 @@ def test_batchnorm_from_the_convolutions_partial_statistics(ops, B, L, Cin, Cout
     zg = z.cpu().view(groups, B // groups, 2 * L, Cout)
     ref = torch.stack([F.relu(F.batch_norm(zg[g].reshape(-1, Cout), None, None, gamma, beta, True, 0.1, 1e-5)) for g in range(groups)])
     close(a1, ref.view(B, 2 * L, Cout), 2e-5)
-    # backward through BatchNorm(+ReLU) of the LAST group, fed by a transposed-convolution data gradient
-    Bg = B // groups
-    zl, al = z[-Bg:].contiguous(), a1[-Bg:].contiguous()
-    mean, invstd = (m1, i1) if groups == 1 else (m1[-1].contiguous(), i1[-1].contiguous())
-    w2 = rnd(Cout, 32, 5, seed=6, scale=0.05)                      # the next layer: ConvTranspose1d(Cout -> 32)
-    dy2 = rnd(Bg, 4 * L, 32, seed=7)
-    wq2 = wq_of(ops, w2, Cout, 32, 32 * 5, 5)                       # its data gradient: gather form, n = Cout, c = 32
-    tb2, rows2 = ops.conv16_plan(Bg, 4 * L, Cout, False)
-    part2 = torch.full((2 * rows2 * Cout,), float("nan"), device="cuda")
-    dyb = torch.empty(Bg, 2 * L, Cout, device="cuda")
-    ops.conv16(dy2.cuda(), wq2, dyb, Cout, False, gref=al, gact=ops.ACT_RELU, stats=(part2, zl, mean, invstd))
-    dz1, dg1, db1 = torch.empty_like(zl), torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
-    ops.bn_train_bwd_parts(part2, rows2, dyb, zl, dz1, gamma.cuda(), mean, invstd, dg1, db1)
-    da = torch.empty_like(zl)
-    ops.conv16(dy2.cuda(), wq2, da, Cout, False)
-    dz2, dg2, db2 = torch.empty_like(zl), torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
-    ops.bn_train_bwd(da, al, zl, dz2, gamma.cuda(), mean, invstd, dg2, db2, ops.ACT_RELU)
-    for got, want in ((dz1, dz2), (dg1, dg2), (db1, db2)):
-        close(got, want.cpu(), 5e-6)
