@@ -38,6 +38,9 @@ B_PER_GPU, T, C = 64, 256, 128
 # the dominant kernel: stride-1 K=3 64x64-tile window GEMM, both weight-layout instantiations (forward / data-gradient)
 DOMINANT = ("conv_wgemm_kernel<1,3,false,true,1,1>", "conv_wgemm_kernel<1,3,false,false,1,1>")
 DOMINANT_NAME = "conv_wgemm_kernel<1,3,false,{true|false},1,1>"
+# second MFMA-bound family, reported beside it: the stride-2 five-tap window GEMMs of the critic and the generator
+CONV16 = ("conv16_kernel<false>", "conv16_kernel<true>")
+CONV16_NAME = "conv16_kernel<{false|true},{1|2}>"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
 # conv+linear FLOPs per sample of one (1D+1G) step at cfg2 as the reference executes it
 MFLOP_PER_SAMPLE = 889.6
@@ -402,9 +405,9 @@ def main():
                      "ms_per_batch": round(1e3 * el5 / (iters * 5), 4)}
 
         # ---- roofline leg: the dominant kernel's launches of one step, recorded and replayed under HIP events ----
-        roof = None
+        roof = roof2 = None
         if rank == 0 and args.profile_steps > 0:
-            hook = RecordHook(DOMINANT)
+            hook = RecordHook(DOMINANT + CONV16)
             ops.set_launch_hook(hook)
             eng.set_batch(*pool[0])
             eng.d_backward_rng()
@@ -413,21 +416,26 @@ def main():
             eng.g_update()
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
-            if hook.records:
+
+            def leg(symbols, name):
+                recs = [r for r in hook.records if r[0] in symbols]
+                if not recs:
+                    return None
                 reps = args.profile_steps
-                ms = time_dominant(ops, hook.records, reps)
-                launches = reps * len(hook.records)
-                flops = reps * sum(r[1] for r in hook.records)
-                # HBM bytes per launch need the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-                # passes, tools/pmc_traffic.py): they cannot be read from inside this process, so the field is null here
-                # and the measured figure lives under profiles/ with the command that produced it
+                ms = time_dominant(ops, recs, reps)
+                launches, flops = reps * len(recs), reps * sum(r[1] for r in recs)
                 achieved = flops / (ms * 1e-3) / 1e12
-                roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
-                            traffic_measured_in="profiles/r02_traffic_dominant_kernel.json (separate rocprofv3 --pmc passes)",
-                            kernel=DOMINANT_NAME,
-                            launches=launches, avg_us=round(1e3 * ms / launches, 2),
+                # HBM bytes per launch need the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+                # tools/pmc_traffic.py): they cannot be read from inside this process, so `traffic` is null here and the
+                # measured figure lives under profiles/ with the command that produced it
+                return dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, kernel=name,
+                            launches=launches, launches_per_step=len(recs), avg_us=round(1e3 * ms / launches, 2),
                             avg_gflop_per_launch=round(flops / launches / 1e9, 3))
+            roof = leg(DOMINANT, DOMINANT_NAME)
+            if roof is not None:
+                roof["traffic_measured_in"] = "profiles/r02_traffic_dominant_kernel.json (separate rocprofv3 --pmc passes)"
+            roof2 = leg(CONV16, CONV16_NAME)
         if rank == 0 and args.launch_flops:
             tally = {}
 
@@ -462,7 +470,8 @@ def main():
                                    "(1 critic update incl. gradient penalty + 1 generator update)",
                        "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
                        "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2)},
-            "event_timing": event_timing, "roofline": roof, "cpu_baseline": cpu, "secondary": sched,
+            "event_timing": event_timing, "roofline": roof, "roofline_stride2_family": roof2, "cpu_baseline": cpu,
+            "secondary": sched,
             "losses": {"loss_d": round(loss_d, 5), "g_adv": round(adv, 5), "g_emo": round(emo, 5)},
         }
         print(json.dumps(line), flush=True)
