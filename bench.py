@@ -39,7 +39,7 @@ B_PER_GPU, T, C = 64, 256, 128
 DOMINANT = ("conv_wgemm_kernel<1,3,false,true,1,1>", "conv_wgemm_kernel<1,3,false,false,1,1>")
 DOMINANT_NAME = "conv_wgemm_kernel<1,3,false,{true|false},1,1>"
 # second MFMA-bound family, reported beside it: the stride-2 five-tap window GEMMs of the critic and the generator
-CONV16 = ("conv16_kernel<false>", "conv16_kernel<true>")
+CONV16 = ("conv16_kernel<false,1>", "conv16_kernel<false,2>", "conv16_kernel<true,1>", "conv16_kernel<true,2>")
 CONV16_NAME = "conv16_kernel<{false|true},{1|2}>"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
 # conv+linear FLOPs per sample of one (1D+1G) step at cfg2 as the reference executes it

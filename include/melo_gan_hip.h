@@ -114,7 +114,7 @@ int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin
  * several BatchNorm groups along the batch needs the group size to be a multiple of batch_rows_per_tile).
  * mg_bn_train_fwd_parts finishes the statistics (fixed order, fp64), moves the running ones and applies: the semantics of
  * mg_bn_train_fwd_groups (nn.BatchNorm1d training forward, src/gan/models.py:57-61) in two launches instead of three. */
-int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows);
+int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows, int* tile_rows);
 int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                     long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream);
 int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups, const float* z, float* a, long R, int C,

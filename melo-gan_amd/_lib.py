@@ -47,7 +47,7 @@ SIGNATURES = {
     "mg_wq_relayout": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "mg_conv16_supported": (i32, [i32, i32, i32, i32, i32, i32]),
     "mg_conv16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
-    "mg_conv16_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "mg_conv16_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "mg_conv16_stats": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, vp]),
     "mg_bn_train_fwd_parts": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp]),
     "mg_linear_workspace_bytes": (sz, [i32, i32, i32]),

@@ -402,15 +402,17 @@ extern "C" int mg_conv16_supported(int B, int Tin, int Cin, int N, int transpose
     return TB * R * 4 <= 256 * MAXX;
 }
 
-// The tiling mg_conv16 picks for a shape: batch rows per tile (a tile never straddles a multiple of it) and the number of
-// partial-statistics rows a launch with `part` writes (2 per workgroup column block: grid.x * 2).
-extern "C" int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows) {
+// The tiling mg_conv16 picks for a shape: batch rows per tile (a tile never straddles a multiple of it), the number of
+// partial-statistics rows a launch with `part` writes (2 per workgroup column block: grid.x * 2), and the positions per
+// tile (64 or 32: which instantiation conv16_kernel<transposed, tile_rows / 32> runs -- lets a profiler label launches).
+extern "C" int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows, int* tile_rows) {
     const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
     const int BM = 32 * pick_rt((long)B * Tm, N);
     int lg = mg_ilog2_ceil(Tm);
     if (lg > mg_ilog2_ceil(BM)) lg = mg_ilog2_ceil(BM);
     const int TT = 1 << lg, TB = BM >> lg;
     if (batch_rows_per_tile) *batch_rows_per_tile = TB;
+    if (tile_rows) *tile_rows = BM;
     if (part_rows) *part_rows = 2 * (int)(mg_cdiv(Tm, TT) * mg_cdiv(B, TB));
     return MG_OK;
 }

@@ -211,9 +211,13 @@ def conv16_supported(B: int, Tin: int, Cin: int, N: int, transposed: bool, Tout:
 
 def conv16_plan(B: int, Tin: int, N: int, transposed: bool):
     """(batch rows one tile spans, partial-statistics rows a launch writes) of mg_conv16's tiling for a shape."""
-    tb, rows = C.c_int(), C.c_int()
-    L.check(L.load().mg_conv16_plan(B, Tin, N, 1 if transposed else 0, C.byref(tb), C.byref(rows)), "mg_conv16_plan")
-    return tb.value, rows.value
+    return _conv16_plan(B, Tin, N, transposed)[:2]
+
+
+def _conv16_plan(B, Tin, N, transposed):
+    tb, rows, bm = C.c_int(), C.c_int(), C.c_int()
+    L.check(L.load().mg_conv16_plan(B, Tin, N, 1 if transposed else 0, C.byref(tb), C.byref(rows), C.byref(bm)), "mg_conv16_plan")
+    return tb.value, rows.value, bm.value
 
 
 def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool = False, stats=None, **epi) -> Tensor:
@@ -245,7 +249,7 @@ def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool
     def launch():
         return lib.mg_conv16_stats(_p(x), _p(wq), _p(y), B, Tin, Cin, N, 1 if transposed else 0, Tout, Tin * Cin,
                                    y.shape[1] * N, C.byref(e), _p(part), _stream())
-    sym = lambda: "conv16_kernel<%s>" % ("true" if transposed else "false")  # noqa: E731
+    sym = lambda: "conv16_kernel<%s,%d>" % ("true" if transposed else "false", _conv16_plan(B, Tin, N, transposed)[2] // 32)  # noqa: E731
     with _observe(sym, 2.0 * B * (Tin if transposed else Tout) * N * Cin * 5, launch):
         rc = launch()
     L.check(rc, "mg_conv16")
