@@ -410,10 +410,7 @@ def main():
             hook = RecordHook(DOMINANT + CONV16)
             ops.set_launch_hook(hook)
             eng.set_batch(*pool[0])
-            eng.d_backward_rng()
-            eng.d_update()
-            eng.g_backward_rng()
-            eng.g_update()
+            dp.step(False)                     # the production launch sequence, eagerly (the hook sees every launch)
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
 
@@ -446,7 +443,7 @@ def main():
                 return ops._NullCtx()
             ops.set_launch_hook(count)
             eng.set_batch(*pool[0])
-            eng.d_backward_rng(); eng.d_update(); eng.g_backward_rng(); eng.g_update()
+            dp.step(False)
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
             with open(args.launch_flops, "w") as f:

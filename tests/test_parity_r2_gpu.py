@@ -189,7 +189,9 @@ def test_batch1_generation_matches_reference(name):
     out = eng.generate(z.cuda(), numeric.cuda()).cpu().numpy()
     np.testing.assert_allclose(eng.emb.cpu().numpy(), g["emb"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(eng.lat.cpu().numpy(), g["latent"], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(out, g["generated"], rtol=1e-3, atol=1e-5)
+    # the fixture's last deconvolution is scaled x1600 (outputs spanning the MIDI writer's branches): every output is a sum of
+    # ~160 products of magnitude ~1, i.e. fp32 summation-order noise of ~3e-5 absolute
+    np.testing.assert_allclose(out, g["generated"], rtol=1e-3, atol=1e-4)
     with torch.cuda.stream(eng.stream):
         gr = ops.Graph()
         gr.begin()
