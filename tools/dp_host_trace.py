@@ -42,7 +42,7 @@ def timed(name, fn):
 
 run0 = eng.run
 eng.run = lambda name, g=True: timed("run:" + name, run0)(name, g)
-for nm in ("allreduce_d", "allreduce_g", "allreduce_g_rest", "gather_p2", "start_d", "start_g_big", "finish_g", "_wait"):
+for nm in ("allreduce_d", "allreduce_g", "allreduce_g_rest", "gather_p2", "_wait"):
     setattr(dp, nm, timed(nm, getattr(dp, nm)))
 N = 200
 with torch.cuda.stream(eng.stream):
