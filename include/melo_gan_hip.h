@@ -135,6 +135,13 @@ int mg_linear(const float* x, const float* w, float* y, int M, int K, int N, int
  * launches by kernel symbol. */
 int mg_conv_tile_config(long m_rows, int N, int scatter2);
 
+/* The layers with a <= 8 channel reduction or output side (NOTE_DIM = 4, reference config/gan_config.yaml:43-44: critic
+ * conv.0 src/gan/models.py:129, generator deconv.6 src/gan/models.py:67-70, emotion discriminator conv0
+ * src/emotion_discriminator/ed_model.py:24, the VAE's first / last layer) do not run on the MFMA tile kernels:
+ * mg_conv1d_gather / mg_conv1d_scatter2 route them to VALU kernels (csrc/conv_thin.hip).  This reports the route a call
+ * takes: 0 = MFMA tile kernel, 1 = thin_in_kernel, 2 / 3 = thin_out_kernel<TR2, 4 / 8>.  MG_CONV_THIN=0 disables it. */
+int mg_conv_thin_route(const float* x, long xbs, int Cin, int N, int K, int stride, int transposed);
+
 /* ---- weight gradient ----
  * out[a][b][k] = sum over segments, batches, u of  S[bt,u,a] * L[bt, u*stride + k - (K-1)/2, b]
  *   S: (nb, Ts, A) "small" tensor, L: (nb, Tl, Bc) "large" tensor (zero outside [0,Tl)).

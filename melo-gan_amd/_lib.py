@@ -53,6 +53,7 @@ SIGNATURES = {
     "mg_linear_workspace_bytes": (sz, [i32, i32, i32]),
     "mg_linear": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_conv_tile_config": (i32, [i64, i32, i32]),
+    "mg_conv_thin_route": (i32, [vp, i64, i32, i32, i32, i32, i32]),
     "mg_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "mg_wgrad": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "mg_wgrad_multi": (i32, [vp, i32, i32, i32, vp, sz, vp]),

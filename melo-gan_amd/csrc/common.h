@@ -137,6 +137,11 @@ __device__ __forceinline__ void mg_apply_epilogue_set(const mg_epilogue& E, floa
     }
 }
 
+// conv_thin.hip: the window GEMMs with a <= 8 channel reduction or output side; MG_EUNSUP = not such a shape
+int mg_conv_thin_dispatch(const float* x, const float* w, float* y, int B, int Tin, int Cin, int Tout, int N, int K, int stride,
+                          int flip, int transposed, int w_sn, int w_sc, long xbs, long ybs, const mg_epilogue* epi,
+                          hipStream_t stream);
+
 static inline int mg_ilog2_ceil(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

@@ -758,6 +758,10 @@ extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B,
       p.w_bytes = wb < (1L << 31) ? wb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (K > 1 && (Cin <= 8 || N <= 8)) {
+        const int rc = mg_conv_thin_dispatch(x, w, y, B, Tin, Cin, Tout, N, K, stride, flip, 0, w_sn, w_sc, p.xbs, p.ybs, &p.e, s);
+        if (rc != MG_EUNSUP) return rc;
+    }
     if (stride == 1) {
         if (K == 1) return launch_gather<1, 1>(p, s);
         if (K == 3) return launch_gather<1, 3>(p, s);
@@ -786,6 +790,10 @@ extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int 
       p.w_bytes = wb < (1L << 31) ? wb : 0; }
     if (int rc = fill_epilogue(p, epi)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (N <= 8) {
+        const int rc = mg_conv_thin_dispatch(x, w, y, B, Tin, Cin, Tout, N, 5, 2, 0, 1, w_sn, w_sc, p.xbs, p.ybs, &p.e, s);
+        if (rc != MG_EUNSUP) return rc;
+    }
     if (scatter_tile((long)B * Tin, N) == 12) return launch_cfg<2, 5, true, 1, 2>(p, s);
     return launch_cfg<2, 5, true, 1, 1>(p, s);
 }

@@ -89,6 +89,9 @@ def _numel(shape):
 # ---------------------------------------------------------------------------------------
 # window GEMMs
 # ---------------------------------------------------------------------------------------
+_THIN_SYMBOLS = {1: "thin_in_kernel%.0s", 2: "thin_out_kernel<%s,4>", 3: "thin_out_kernel<%s,8>"}
+
+
 def _conv_work(lib, B, Tout, N, Cin, device):
     """Split-K scratch for small-output convolutions (only they can use it: <= 8 MB of output)."""
     if Cin < 64 or B * Tout * N > (1 << 21):
@@ -117,9 +120,13 @@ def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_
     if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
     lib = L.load()
-    sym = lambda: "conv_wgemm_kernel<%d,%d,false,%s,%s>" % (  # noqa: E731  (S, K, TR2, NCK weight layout, tile)
-        stride, K, "true" if w_sc < w_sn else "false",
-        {22: "2,2", 12: "1,2", 11: "1,1"}[lib.mg_conv_tile_config(B * Tout, N, 0)])
+    def sym():
+        thin = lib.mg_conv_thin_route(_p(x), Tin * Cin, Cin, N, K, stride, 0)
+        if thin:
+            return _THIN_SYMBOLS[thin] % "false"
+        return "conv_wgemm_kernel<%d,%d,false,%s,%s>" % (            # (S, K, TR2, NCK weight layout, tile)
+            stride, K, "true" if w_sc < w_sn else "false",
+            {22: "2,2", 12: "1,2", 11: "1,1"}[lib.mg_conv_tile_config(B * Tout, N, 0)])
     work = _conv_work(lib, B, Tout, N, Cin, x.device)
     def launch():
         return lib.mg_conv1d_gather(_p(x), _p(w), _p(y), B, Tin, Cin, N, K, stride, 1 if flip else 0, w_sn, w_sc,
@@ -148,8 +155,12 @@ def conv_scatter2(x: Tensor, w: Tensor, y: Tensor, N: int, w_sn: int, w_sc: int,
     if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
     lib = L.load()
-    sym = lambda: "conv_wgemm_kernel<2,5,true,%s,%s>" % (  # noqa: E731
-        "true" if w_sc < w_sn else "false", "1,2" if lib.mg_conv_tile_config(B * Tin, N, 1) == 12 else "1,1")
+    def sym():
+        thin = lib.mg_conv_thin_route(_p(x), Tin * Cin, Cin, N, 5, 2, 1)
+        if thin:
+            return _THIN_SYMBOLS[thin] % "true"
+        return "conv_wgemm_kernel<2,5,true,%s,%s>" % (
+            "true" if w_sc < w_sn else "false", "1,2" if lib.mg_conv_tile_config(B * Tin, N, 1) == 12 else "1,1")
     work = _conv_work(lib, B, Tout, N, Cin, x.device)
     with _observe(sym, 2.0 * B * Tin * N * Cin * 5):
         rc = lib.mg_conv1d_scatter2(_p(x), _p(w), _p(y), B, Tin, Cin, N, Tout, w_sn, w_sc, Tin * Cin, y.shape[1] * N,
