@@ -5,6 +5,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmelogan_hip.so")
+if os.environ.get("MELO_LIB_VARIANT"):      # A/B measurements: a tools/build_variant.sh build of the same sources
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_build", "libmelogan_" + os.environ["MELO_LIB_VARIANT"] + ".so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3, 4
 

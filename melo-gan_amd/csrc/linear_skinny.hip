@@ -20,6 +20,7 @@ struct LinP {
     int M, K, N;
     int w_sn, w_sc;
     int ksplit;
+    int gx, gy;       // row / column tiles
     int kw;           // K range per wave (multiple of 8)
     mg_epilogue e;
 };
@@ -32,10 +33,14 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(const LinP p) {
     __shared__ float tile[NW][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    // 1-D launch, XCD remap: the row tiles of one column tile (same weight tile) and neighbouring column tiles get
+    // consecutive logical ids -> one L2: pre.2's 16.8 MB of weights cross the fabric once, not once per row tile
+    const int id = mg_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int bx = id % p.gx, byz = id / p.gx, by = byz % p.gy, bz = byz / p.gy;
+    const int m0 = bx * 32, n0 = by * 32;
     const int row = min(m0 + i, p.M - 1);          // clamped: out-of-range rows/cols are computed but never stored
     const int col = min(n0 + i, p.N - 1);
-    const int kbeg = (blockIdx.z * NW + wave) * p.kw;
+    const int kbeg = (bz * NW + wave) * p.kw;
     const int kend = min(kbeg + p.kw, p.K);
     const float* xr = p.x + (long)row * p.K;
     const float* wr = p.w + (long)col * p.w_sn;
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(const LinP p) {
     if (p.ksplit > 1) {
 #pragma unroll
         for (int q = 0; q < NV; ++q)
-            if (ok[q]) p.part[(long)blockIdx.z * p.M * p.N + di[q]] = v[q];
+            if (ok[q]) p.part[(long)bz * p.M * p.N + di[q]] = v[q];
         return;
     }
     mg_apply_epilogue_set<NV>(p.e, v, nn, di, ok);
@@ -196,7 +201,8 @@ extern "C" int mg_linear(const float* x, const float* w, float* y, int M, int K,
         if (!work || work_bytes < need) { mg_set_error("mg_linear: workspace too small (%zu < %zu)", work_bytes, need); return MG_EWORK; }
         p.part = (float*)work;
     }
-    dim3 grid((unsigned)mg_cdiv(M, 32), (unsigned)mg_cdiv(N, 32), (unsigned)p.ksplit);
+    p.gx = (int)mg_cdiv(M, 32); p.gy = (int)mg_cdiv(N, 32);
+    dim3 grid((unsigned)(p.gx * p.gy * p.ksplit));
     hipStream_t st = (hipStream_t)stream;
     if (kcontig) {
         if (vec) hipLaunchKernelGGL((linear_skinny_kernel<true, true>), grid, dim3(64 * NW), 0, st, p);
