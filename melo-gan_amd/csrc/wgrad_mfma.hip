@@ -38,6 +38,7 @@ struct WgradP {
     int bias_from;  // 0: none; 1: column sums of S (Conv1d / Linear bias); 2: column sums of L (ConvTranspose1d bias)
     int nseg_bias;  // how many segments contribute to the bias (penalty segment never does)
     int vec_ok;     // all four tensors 16-byte aligned and < 2 GiB (raw-buffer float4 path)
+    int gx, gy, gz; // output tiles along A and Bc, slices; the launch starts with gz * ceil(C / 32) bias workgroups (bias_from != 0)
 };
 
 constexpr int RT = 64;            // reduction rows per LDS chunk (16 per wave)
@@ -103,25 +104,6 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
                 acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lrow[k * BB], acc[k], 0, 0, 0);
         }
     };
-
-    // bias gradient fused in: per chunk every thread adds its share of the staged rows' column sums
-    float bsum = 0.f;
-    const bool do_bias_s = p.bias_from == 1 && by == 0;
-    const bool do_bias_l = p.bias_from == 2 && bx == 0;
-    auto bias_accum_at = [&](int boff, int seg_id) {
-        if (seg_id >= p.nseg_bias) return;
-        const int cx = tid & 31, rq = tid >> 5;      // 32 channels x 8 row lanes
-        if (do_bias_s) {
-#pragma unroll
-            for (int r = rq; r < RT; r += 8) bsum += Ss[boff + r * BA + cx];
-        } else if (do_bias_l) {
-            // each L row belongs to exactly one chunk: window rows [PAD, PAD + TT*S) of every segment
-            for (int seg = 0; seg < TB; ++seg)
-                for (int rr = PAD + rq; rr < PAD + TT * S; rr += 8) bsum += Ls[boff + (seg * R + rr) * BB + cx];
-        }
-    };
-
-    auto bias_accum = [&](int seg_id) { bias_accum_at(0, seg_id); };
 
     const bool fast = ((p.A & 3) == 0) && ((p.Bc & 3) == 0) && p.vec_ok && (lrows * (BB / 4) <= 256 * NL4);
     if (fast && p.tt_log2 >= 4 && n_chunks > 0) {
@@ -221,7 +203,6 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
         auto chunk = [&](auto parity, int c) {
             constexpr int P = decltype(parity)::value;
             const int cur = P ? buf_floats : 0, oth = buf_floats - cur;
-            bias_accum_at(cur, (g_begin + c / p.n_ttiles) < p.nbg0 ? 0 : 1);
             chunk_addr(min(c + 2, n_chunks - 1));    // addresses of the chunk the reloads below fetch
 #pragma unroll
             for (int m = 0; m < NR2 * K; ++m) {
@@ -332,7 +313,6 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
 #ifndef MG_EXP_NOLOADS
                 if (more) load_chunk(c + 1);
 #endif
-                bias_accum((g_begin + c / p.n_ttiles) < p.nbg0 ? 0 : 1);
                 compute();
                 __syncthreads();
                 if (more) {
@@ -370,7 +350,6 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
                     Ls[row * BB + cl] = v;
                 }
                 __syncthreads();
-                bias_accum(seg_id);
                 compute();
             }
         }
@@ -385,48 +364,103 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
     if (acc[0][0] != 12345.f) return;
 #endif
     MG_STAMP(2);
-    __syncthreads();
-    float* red = smem;                                   // [4][K][32][33]
+    float* red = smem;                                   // [4][KP][32][33]
     float* out = p.part ? p.part + (long)split * p.slab : p.out;
+    // In passes of KP <= 3 taps: parking all K = 5 taps at once takes 4*5*32*33*4 = 84 KB of LDS -- more than the two
+    // staging buffers (54 KB) and the reason only ONE workgroup fitted a CU.  With KP = 3 the epilogue fits the staging
+    // allocation and two workgroups share a CU: the bias workgroups of the launch (wgrad_bias_body) run beside the tile
+    // workgroups instead of taking whole CUs.  Summation order per element unchanged: (w0 + w1) + (w2 + w3).
+    constexpr int KP = K > 3 ? 3 : K;
+    const int nb_cols = min(32, p.Bc - b0);
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            red[((wave * K + k) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 33 + (lane & 31)] = acc[k][r];
-    __syncthreads();
-    {
-        const int nb_valid = min(32, p.Bc - b0) * K;     // floats per row of this tile that exist in `out`
-#pragma unroll 4
-        for (int idx = tid; idx < 32 * K * 32; idx += 256) {
-            const int ar = idx / (K * 32), j = idx - ar * (K * 32);
-            const int bc = j / K, k = j - bc * K;
-            const int a = a0 + ar;
-            const int o = (k * 32 + ar) * 33 + bc;
-            const float v = (red[o] + red[o + K * 32 * 33]) + (red[o + 2 * K * 32 * 33] + red[o + 3 * K * 32 * 33]);
-            if (a < p.A && j < nb_valid) out[((long)a * p.Bc + b0) * K + j] = v;
-        }
-    }
-    __syncthreads();
-    if (do_bias_s || do_bias_l) {        // 8 row-lane partials -> one value per channel of this tile
-        red[tid] = bsum;
+    for (int k0 = 0; k0 < K; k0 += KP) {
+        const int kn = (K - k0) < KP ? (K - k0) : KP;    // taps of this pass (compile-time after unrolling)
         __syncthreads();
-        if (tid < 32) {
-            const int ch = (do_bias_s ? a0 : b0) + tid;
-            if (ch < (do_bias_s ? p.A : p.Bc)) {
-                float v = 0.f;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) v += red[tid + 32 * g];
-                if (p.part) out[p.wslab + ch] = v;
-                else p.bias_out[ch] = v;
-            }
+        for (int k = k0; k < k0 + kn; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[((wave * KP + (k - k0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 33 + (lane & 31)] = acc[k][r];
+        __syncthreads();
+#pragma unroll 4
+        for (int idx = tid; idx < 32 * kn * 32; idx += 256) {
+            const int ar = idx / (kn * 32), j = idx - ar * (kn * 32);
+            const int bc = j / kn, kk = j - bc * kn;
+            const int a = a0 + ar;
+            const int o = (kk * 32 + ar) * 33 + bc;
+            const float v = (red[o] + red[o + KP * 32 * 33]) + (red[o + 2 * KP * 32 * 33] + red[o + 3 * KP * 32 * 33]);
+            if (a < p.A && bc < nb_cols) out[((long)a * p.Bc + b0 + bc) * K + k0 + kk] = v;
         }
     }
     MG_STAMP(3);
 }
 
+// The bias gradient -- column sums of S (Conv1d / Linear: bias_from 1) or of L (ConvTranspose1d: 2) over the segments
+// that carry one -- is the work of EXTRA workgroups of the same launch, one per (slice, 32-column block): a streaming
+// sum of the slice's rows (a few hundred rows x 128 B, ~1-2 us) into the slab's bias entries, which the slab reduction
+// adds like the weight entries.  Round 1 had the tile workgroups of one tile row / column add up the rows they staged,
+// at the head of every chunk: 8-16 dependent LDS reads ahead of the chunk's first MFMA in a quarter of the workgroups,
+// which then finished last -- 20 us per training step.
+__device__ __forceinline__ void wgrad_bias_body(const WgradP& p, const int cb, const int bz) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* bred = reinterpret_cast<f32x4*>(smem);          // 4 KB of the launch's dynamic allocation
+    const int tid = threadIdx.x, q = tid & 7, rl = tid >> 3;          // column quad, row lane (32 of them)
+    const bool from_s = p.bias_from == 1;
+    const int C = from_s ? p.A : p.Bc, T = from_s ? p.Ts : p.Tl;
+    const int TB = RT >> p.tt_log2;
+    const int g_begin = bz * p.bps, g_end = min(g_begin + p.bps, p.n_bgroups);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int c = cb * 32 + 4 * q;
+    for (int seg = 0; seg < p.nseg_bias && seg < 2; ++seg) {
+        // batch rows of this slice inside segment `seg`
+        const int gs = seg ? p.nbg0 : 0, ge = seg ? p.n_bgroups : p.nbg0;
+        const int ga = max(g_begin, gs), gb = min(g_end, ge);
+        if (ga >= gb) continue;
+        const int b_lo = (ga - gs) * TB, b_hi = min((gb - gs) * TB, p.nb[seg]);
+        const float* base = (from_s ? p.s[seg] : p.l[seg]) + (long)b_lo * T * C;
+        const long rows = (long)(b_hi - b_lo) * T;
+        if (c + 3 < C && (C & 3) == 0 && p.vec_ok) {
+            long r = rl;
+            for (; r + 32 * 7 < rows; r += 32 * 8) {          // eight rows in flight per thread: the loop is latency-bound
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (r + 32 * u) * C + c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; r < rows; r += 32) acc += *reinterpret_cast<const f32x4*>(base + r * C + c);
+        } else {
+            for (long r = rl; r < rows; r += 32)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) acc[e] += base[r * C + c + e];
+        }
+    }
+    bred[tid] = acc;
+    __syncthreads();
+    if (tid < 32) {
+        const int ch = cb * 32 + tid;
+        if (ch < C) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int g = 0; g < 32; ++g) v += bred[8 * g + (tid >> 2)][tid & 3];
+            if (p.part) p.part[(long)bz * p.slab + p.wslab + ch] = v;
+            else p.bias_out[ch] = v;
+        }
+    }
+}
+
 template <int S, int K>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
-    wgrad_body<S, K>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    const int ncb = p.bias_from ? ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5 : 0, nbias = ncb * p.gz;
+    const int id = (int)blockIdx.x - nbias, gxy = p.gx * p.gy;
+    if (id >= 0) {
+        const int bz = id / gxy, r = id - bz * gxy;
+        wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
+    } else {
+        const int k = (int)blockIdx.x;
+        wgrad_bias_body(p, k % ncb, k / ncb);
+    }
 }
 
 // Several independent weight gradients of one (stride, K) in ONE launch: the small layers' gradients are each a
@@ -435,7 +469,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
 struct WgradJobs {
     WgradP p[MG_MAX_WGRAD_JOBS];
     int first[MG_MAX_WGRAD_JOBS + 1];
-    int gx[MG_MAX_WGRAD_JOBS], gy[MG_MAX_WGRAD_JOBS];
     int n;
 };
 template <int S, int K>
@@ -443,10 +476,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgradJobs J) 
     int j = 0;
     while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;       // uniform
     const int b = (int)blockIdx.x - J.first[j];
-    const int gx = J.gx[j], gxy = gx * J.gy[j];
-    const int bz = b / gxy, r = b - bz * gxy;
-    const WgradP p = J.p[j];
-    wgrad_body<S, K>(p, r % gx, r / gx, bz);
+    const WgradP& p = J.p[j];          // a reference: the by-value copy landed in scratch memory once two bodies used it
+    const int ncb = p.bias_from ? ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5 : 0, nbias = ncb * p.gz;
+    const int id = b - nbias, gxy = p.gx * p.gy;
+    if (id >= 0) {
+        const int bz = id / gxy, r = id - bz * gxy;
+        wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
+    } else {
+        wgrad_bias_body(p, b % ncb, b / ncb);
+    }
 }
 
 // out[i] = sum_z part[z][i]; 64 elements x 4 slice-groups per block (fixed summation order => reproducible).
@@ -505,7 +543,8 @@ struct Plan {
 
 constexpr int MAX_SPLITS = 32;
 
-Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
+// want_slices > 0: the launch-level planner of mg_wgrad_multi has decided the slice count (clamped to what the job allows)
+Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts, long want_slices = 0) {
     Plan pl;
     int lg = mg_ilog2_ceil(Ts);
     const int lgrt = mg_ilog2_ceil(RT);
@@ -521,7 +560,7 @@ Plan make_plan(int A, int Bc, int K, int nb0, int nb1, int Ts) {
     long target = 256;      // one workgroup per CU: the gap-scheduled loop overlaps its own staging, and fewer slices
                             // mean fewer prologues / cross-wave epilogues per CU and fewer slabs to reduce
     if (const char* f = getenv("MG_WGRAD_TARGET")) target = atol(f);
-    long want = mg_cdiv(target, tiles);
+    long want = want_slices > 0 ? want_slices : mg_cdiv(target, tiles);
     long max_by_work = ((long)ngroups * pl.n_ttiles) / 2;
     if (max_by_work < 1) max_by_work = 1;
     if (want > max_by_work) want = max_by_work;
@@ -558,7 +597,7 @@ namespace {
 // `work` is where THIS job's partial slabs go (used only when the plan splits).
 int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, const float* l1, int nb1, float* out,
                 float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride, void* work,
-                size_t work_bytes, WgradP& p, Plan& pl, size_t& lds, dim3& grid) {
+                size_t work_bytes, WgradP& p, Plan& pl, size_t& lds, dim3& grid, long want_slices = 0) {
     MG_CHECK_ARG(bias_from >= 0 && bias_from <= 2 && ((bias_from == 0) == (bias_out == nullptr)),
                  "mg_wgrad: bias_out and bias_from (1: sums of S, 2: sums of L) must be given together");
     MG_CHECK_ARG(s0 && l0 && out && nb0 > 0, "mg_wgrad: null/empty segment 0");
@@ -570,7 +609,7 @@ int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, cons
         mg_set_error("mg_wgrad: stride 2 needs K=5");
         return MG_EUNSUP;
     }
-    pl = make_plan(A, Bc, K, nb0, nb1, Ts);
+    pl = make_plan(A, Bc, K, nb0, nb1, Ts, want_slices);
     const long wslab = (long)A * Bc * K;
     const long slab = wslab + (bias_from == 1 ? A : bias_from == 2 ? Bc : 0);
     if (pl.nsplit > 1 && (!work || work_bytes < (size_t)pl.nsplit * slab * sizeof(float))) {
@@ -593,13 +632,15 @@ int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, cons
     const int TT = 1 << pl.tt_log2;
     const int R = (TT - 1) * stride + K;
     size_t lds_floats = 2 * ((size_t)RT * BA + (size_t)pl.TB * R * BB) + 256 * 4;   // two buffers + the staging sink
-    const size_t epi_floats = (size_t)4 * K * 32 * 33;     // the final cross-wave reduction reuses the buffer
+    const size_t epi_floats = (size_t)4 * (K > 3 ? 3 : K) * 32 * 33;     // the cross-wave reduction (passes of <= 3 taps) reuses the buffers
     if (lds_floats < epi_floats) lds_floats = epi_floats;
     lds = lds_floats * sizeof(float);
     auto ok = [](const float* q, long elems) { return q == nullptr || (((((uintptr_t)q) & 15) == 0) && elems * 4 < (1L << 31)); };
     p.vec_ok = ok(s0, (long)nb0 * Ts * A) && ok(l0, (long)nb0 * Tl * Bc) && ok(nb1 ? s1 : nullptr, (long)nb1 * Ts * A) &&
                ok(nb1 ? l1 : nullptr, (long)nb1 * Tl * Bc);
-    grid = dim3((unsigned)mg_cdiv(A, BA), (unsigned)mg_cdiv(Bc, BB), (unsigned)pl.nsplit);
+    p.gx = (int)mg_cdiv(A, BA); p.gy = (int)mg_cdiv(Bc, BB); p.gz = pl.nsplit;
+    const int nbias = bias_from ? pl.nsplit * (int)mg_cdiv(bias_from == 1 ? A : Bc, 32) : 0;
+    grid = dim3((unsigned)(p.gx * p.gy * p.gz + nbias));      // 1-D: the bias workgroups, then the tile workgroups
     return MG_OK;
 }
 }  // namespace
@@ -638,6 +679,39 @@ extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int s
     ReduceJobs Rj{};
     size_t lds_max = 0, used = 0;
     int nblocks = 0, rblocks = 0;
+    // Launch-level plan: the jobs' workgroups share ONE pass over the chip, so the slice counts
+    // are chosen together -- every workgroup gets about the same number of 64-row chunks and the total stays within
+    // `target` workgroups.  (Planned job by job, ~256 workgroups each, the critic's three gradients were 768 workgroups =
+    // three rounds of prologue + loop + epilogue per CU, and the jobs' workgroups differed 2x in length.)
+    long want[MG_MAX_WGRAD_JOBS];
+    {
+        long target = 512;       // two workgroups per CU (54 KB of LDS each), all resident at once.  Measured, critic's three
+                                 // 3B-row gradients / generator's three deconvolutions / training step: 256: 101 / 44 us,
+                                 // 384: 77 / 38, 512: 72 / 37 (1.031 ms), 640: 78 / 41 (1.041), 768: 83 / 41, 1024: 78 / 44;
+                                 // the per-job plan it replaces (~256 each, 768 in all): 82 / 51 (1.058 ms)
+        if (const char* f = getenv("MG_WGRAD_TARGET")) target = atol(f);
+        long tiles[MG_MAX_WGRAD_JOBS], chunks[MG_MAX_WGRAD_JOBS], total = 0;
+        for (int i = 0; i < n_jobs; ++i) {
+            const mg_wgrad_job& q = jobs[i];
+            const Plan pl = make_plan(q.A, q.Bc, K, q.nb0, q.nb1, q.Ts);
+            tiles[i] = mg_cdiv(q.A, BA) * mg_cdiv(q.Bc, BB);
+            chunks[i] = (long)(pl.nbg0 + pl.nbg1) * pl.n_ttiles;        // per tile
+            total += tiles[i] * chunks[i];
+        }
+        long cpw = mg_cdiv(total, target);                               // chunks per workgroup
+        for (int it = 0; it < 64; ++it) {
+            long wgs = 0;
+            for (int i = 0; i < n_jobs; ++i) {
+                const mg_wgrad_job& q = jobs[i];
+                want[i] = (chunks[i] + cpw / 2) / cpw;
+                if (want[i] < 1) want[i] = 1;
+                const Plan pl = make_plan(q.A, q.Bc, K, q.nb0, q.nb1, q.Ts, want[i]);
+                wgs += tiles[i] * pl.nsplit;
+            }
+            if (wgs <= target) break;
+            cpw += mg_cdiv(cpw, 16);
+        }
+    }
     for (int i = 0; i < n_jobs; ++i) {
         const mg_wgrad_job& q = jobs[i];
         Plan pl;
@@ -647,7 +721,7 @@ extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int s
         const size_t need = mg_wgrad_workspace_bytes(q.A, q.Bc, K, q.nb0 + q.nb1, q.Ts);
         void* w = used < work_bytes && work ? (char*)work + used : nullptr;
         const int rc = build_wgrad(q.s0, q.l0, q.nb0, q.s1, q.l1, q.nb1, q.out, q.bias_out, q.bias_from, q.Ts, q.Tl, q.A,
-                                   q.Bc, K, stride, w, w ? work_bytes - used : 0, J.p[i], pl, lds, grid);
+                                   q.Bc, K, stride, w, w ? work_bytes - used : 0, J.p[i], pl, lds, grid, want[i]);
         if (rc != MG_OK) return rc;
         if (pl.nsplit > 1) {
             used += (need + 255) & ~(size_t)255;
@@ -659,8 +733,7 @@ extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int s
         }
         lds_max = lds > lds_max ? lds : lds_max;
         J.first[i] = nblocks;
-        J.gx[i] = (int)grid.x; J.gy[i] = (int)grid.y;
-        nblocks += (int)(grid.x * grid.y * grid.z);
+        nblocks += (int)grid.x;
     }
     J.first[n_jobs] = nblocks;
     J.n = n_jobs;

@@ -367,9 +367,11 @@ def test_tick_free_draw_and_update_match_the_plain_pair(ops):
 
 
 def test_wgrad_multi_equals_separate_launches():
-    """mg_wgrad_multi: several weight gradients per launch are bit-identical to one launch each (same workgroup body,
-    same split plan, same reduction order): Linear layers (unsplit), stride-2 K=5 conv / convT gradients with fused
-    bias sums and batch splits, a two-segment job, ragged channel counts, and more jobs than one launch holds."""
+    """mg_wgrad_multi: several weight gradients per launch equal one launch each -- bit for bit where the reduction is
+    not split over workgroups (the Linear layers), to fp32 summation-order noise where it is (the multi launch plans the
+    slice counts of its jobs TOGETHER, so a job's slices differ from its stand-alone plan) -- and the multi launch is
+    itself bitwise reproducible: Linear layers, stride-2 K=5 conv / convT gradients with fused bias sums and batch
+    splits, a two-segment job, ragged channel counts, and more jobs than one launch holds."""
     import melo_gan_amd  # noqa: F401
     from melo_gan_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -396,9 +398,20 @@ def test_wgrad_multi_equals_separate_launches():
         x, dy, dw, db = r(B, T, ci), r(B, T // 2, co), torch.empty(co, ci, 5).cuda(), torch.empty(co).cuda()
         both(ops.conv1d_wgrad, x, dy, dw, 2, db=db, outs=[dw, db])
     ops.wgrad_multi([j for j, _ in jobs])
-    for (_, outs), ws in zip(jobs, want):
+    first = [[o.clone() for o in outs] for _, outs in jobs]
+    for (job, outs), ws in zip(jobs, want):
         for o, w in zip(outs, ws):
-            assert torch.equal(o, w)
+            if job[13] == 1:                     # K = 1: one slice either way
+                assert torch.equal(o, w)
+            else:
+                torch.testing.assert_close(o, w, rtol=2e-5, atol=2e-5 * float(w.abs().max()))
+    for _, outs in jobs:
+        for o in outs:
+            o.fill_(float("nan"))
+    ops.wgrad_multi([j for j, _ in jobs])
+    for (_, outs), fs in zip(jobs, first):
+        for o, f in zip(outs, fs):
+            assert torch.equal(o, f)
 
 
 def test_transpose_with_activation_backward():
