@@ -134,24 +134,32 @@ __device__ __forceinline__ void mg_apply_epilogue_set(const mg_epilogue& E, floa
 #pragma unroll
         for (int q = 0; q < NV; ++q) v[q] = mg_act(MG_ACT_TANH, v[q]);
     }
+    // elementwise operands: unconditional clamped loads (all in flight), applied afterwards -- a load behind `if (ok)`
+    // compiles to branch + load + wait per element
     if (E.gref) {
+        float g[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) g[q] = E.gref[ok[q] ? di[q] : 0];
         if (E.gact == MG_ACT_RELU) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_RELU, E.gref[di[q]]);
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_RELU, g[q]);
         } else if (E.gact == MG_ACT_LRELU) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_LRELU, E.gref[di[q]]);
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_LRELU, g[q]);
         } else if (E.gact == MG_ACT_GELU) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_GELU, E.gref[di[q]]);
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_GELU, g[q]);
         } else if (E.gact == MG_ACT_TANH) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= mg_act_grad(MG_ACT_TANH, E.gref[di[q]]);
+            for (int q = 0; q < NV; ++q) v[q] *= mg_act_grad(MG_ACT_TANH, g[q]);
         }
     }
     if (E.emul) {
+        float g[NV];
 #pragma unroll
-        for (int q = 0; q < NV; ++q) if (ok[q]) v[q] *= E.emul[di[q]];
+        for (int q = 0; q < NV; ++q) g[q] = E.emul[ok[q] ? di[q] : 0];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] *= g[q];
     }
     if (E.gscale) {
 #pragma unroll

@@ -271,29 +271,32 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] = mg_act(MG_ACT_TANH, a[r]);
             }
+            // elementwise operands: unconditional row-clamped loads, all in flight, applied afterwards (behind `if (ok)`
+            // hipcc emitted branch + load + wait per element); rows outside the tensor are never stored
             if (E.gref) {
+                float g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = E.gref[ok[r] ? di[r] : 0u];
                 if (E.gact == MG_ACT_RELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_RELU, E.gref[di[r]]);
+                    for (int r = 0; r < 4; ++r) a[r] *= mg_act_grad(MG_ACT_RELU, g[r]);
                 } else if (E.gact == MG_ACT_LRELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_LRELU, E.gref[di[r]]);
+                    for (int r = 0; r < 4; ++r) a[r] *= mg_act_grad(MG_ACT_LRELU, g[r]);
                 } else if (E.gact == MG_ACT_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_GELU, E.gref[di[r]]);
+                    for (int r = 0; r < 4; ++r) a[r] *= mg_act_grad(MG_ACT_GELU, g[r]);
                 } else if (E.gact == MG_ACT_TANH) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ok[r]) a[r] *= mg_act_grad(MG_ACT_TANH, E.gref[di[r]]);
+                    for (int r = 0; r < 4; ++r) a[r] *= mg_act_grad(MG_ACT_TANH, g[r]);
                 }
             }
             if (E.emul) {
+                float g[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ok[r]) a[r] *= E.emul[di[r]];
+                for (int r = 0; r < 4; ++r) g[r] = E.emul[ok[r] ? di[r] : 0u];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] *= g[r];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] *= gscale;
@@ -306,9 +309,11 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
                     }
             }
             if (E.accumulate) {
+                float g[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ok[r]) a[r] += p.y[yi[r]];
+                for (int r = 0; r < 4; ++r) g[r] = p.y[ok[r] ? yi[r] : 0u];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] += g[r];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)

@@ -522,29 +522,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) a[r] = mg_act(MG_ACT_TANH, a[r]);
                 }
+                // Elementwise operands are loaded UNCONDITIONALLY, row-clamped (element 0 always exists), all sixteen in
+                // flight, and applied afterwards: behind `if (row is inside)` hipcc emitted branch + load + wait per
+                // element -- sixteen dependent memory round trips, 8-12 us of the emotion discriminator's data-gradient
+                // launches.  Values of rows outside the tensor are never stored.
                 if (E.gref) {
+                    float g[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g[r] = E.gref[index(r, di, yi) ? di : 0u];
                     if (E.gact == MG_ACT_RELU) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_RELU, E.gref[di]);
+                        for (int r = 0; r < 16; ++r) a[r] *= mg_act_grad(MG_ACT_RELU, g[r]);
                     } else if (E.gact == MG_ACT_LRELU) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_LRELU, E.gref[di]);
+                        for (int r = 0; r < 16; ++r) a[r] *= mg_act_grad(MG_ACT_LRELU, g[r]);
                     } else if (E.gact == MG_ACT_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_GELU, E.gref[di]);
+                        for (int r = 0; r < 16; ++r) a[r] *= mg_act_grad(MG_ACT_GELU, g[r]);
                     } else if (E.gact == MG_ACT_TANH) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (index(r, di, yi)) a[r] *= mg_act_grad(MG_ACT_TANH, E.gref[di]);
+                        for (int r = 0; r < 16; ++r) a[r] *= mg_act_grad(MG_ACT_TANH, g[r]);
                     }
                 }
                 if (E.emul) {
+                    float g[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (index(r, di, yi)) a[r] *= E.emul[di];
+                    for (int r = 0; r < 16; ++r) g[r] = E.emul[index(r, di, yi) ? di : 0u];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] *= g[r];
                 }
                 if (E.gscale) {
                     const float gscale = E.gscale[n];
@@ -552,9 +557,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                     for (int r = 0; r < 16; ++r) a[r] *= gscale;
                 }
                 if (E.accumulate) {
+                    float g[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (index(r, di, yi)) a[r] += p.y[yi];
+                    for (int r = 0; r < 16; ++r) g[r] = p.y[index(r, di, yi) ? yi : 0u];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] += g[r];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
