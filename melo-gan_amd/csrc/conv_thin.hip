@@ -48,21 +48,35 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinP p) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float* xb = p.x + (long)b * p.xbs;
     const bool x4 = p.Cin == 4 && (p.xbs & 3) == 0 && ((((uintptr_t)p.x) & 15) == 0);
-    for (int k = 0; k < p.K; ++k) {
-        const int tin = tin0 + k;
-        if (tin < 0 || tin >= p.Tin) continue;
-        const float* xr = xb + (long)tin * p.Cin;
-        if (x4) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr);
+    if (x4) {
+        // the window's rows as five unconditional row-clamped 16-byte loads, all in flight, zeroed afterwards where the
+        // row lies outside the sequence (a load behind a per-lane condition costs a branch and a wait each)
+        f32x4 xv[TK];
+#pragma unroll
+        for (int k = 0; k < TK; ++k) {
+            const int tin = tin0 + k;
+            const bool ok = k < p.K && tin >= 0 && tin < p.Tin;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)(ok ? tin : 0) * 4);
+            xv[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < TK; ++k) {
+            if (k >= p.K) break;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(&Wl[k * 4 + c][4 * nq]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += xv[c] * w[e];
+                for (int e = 0; e < 4; ++e) acc[e] += xv[k][c] * w[e];
             }
-        } else {
+        }
+    } else {
+        for (int k = 0; k < p.K; ++k) {
+            const int tin = tin0 + k;
+            const bool ok = tin >= 0 && tin < p.Tin;
+            const float* xr = xb + (long)(ok ? tin : 0) * p.Cin;
             for (int c = 0; c < p.Cin; ++c) {
-                const float xv = xr[c];
+                const float xl = xr[c];
+                const float xv = ok ? xl : 0.f;
                 const f32x4 w = *reinterpret_cast<const f32x4*>(&Wl[k * p.Cin + c][4 * nq]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += xv * w[e];
