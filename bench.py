@@ -59,6 +59,9 @@ def parse():
                     help="replays of the dominant kernel's launches (one step's worth each) for the roofline leg; 0 = skip")
     ap.add_argument("--launch-flops", default=None, metavar="FILE",
                     help="write {kernel symbol: launches and GFLOP per step} of one eager step to FILE (tools/pmc_mfma_busy.py)")
+    ap.add_argument("--ed-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: the SECONDARY configuration -- the frozen emotion discriminator's activations and folded "
+                         "weights stored in bf16, fp32 accumulate (reported with its own dtype string, never the headline)")
     ap.add_argument("--workload", default="gan", choices=["gan", "ae", "gen1", "ed"],
                     help="gan: the headline cfg2 step (default); ae: BASELINE config 4 (VAE step, B=256, T=256, C=4); "
                          "gen1: BASELINE config 5 (batch-1 E_num->G generation latency); ed: emotion-discriminator "
@@ -315,7 +318,7 @@ def main():
     from melo_gan_amd.gan.config import default_gan_cfg, default_ed_cfg
 
     cfg, ed_cfg = default_gan_cfg(B_PER_GPU, T, C), default_ed_cfg(C)
-    eng = GanEngine(cfg, ed_cfg, f"cuda:{local_rank}", B_PER_GPU)
+    eng = GanEngine(cfg, ed_cfg, f"cuda:{local_rank}", B_PER_GPU, ed_dtype=args.ed_dtype)
     eng.init_weights(seed=42)                       # identical on every rank
     dp = DataParallel(eng, world, dist if dist_on else None, force_collectives=force_dp)
     dp.broadcast_params()
@@ -450,6 +453,40 @@ def main():
                 json.dump(tally, f, indent=1)
         loss_d, adv, emo = eng.loss_d_out[0].item(), eng.adv.item(), eng.emo.item()
 
+    # ---- secondary configuration beside the fp32 headline (BASELINE.json configs[1] names bf16): the same step with the
+    # frozen emotion discriminator's activations / folded weights STORED in bf16 (fp32 accumulate); all trained state fp32 ----
+    sec = None
+    if rank == 0 and world == 1 and args.ed_dtype == "fp32" and args.profile_steps > 0 and use_graph:
+        try:
+            eng2 = GanEngine(cfg, ed_cfg, f"cuda:{local_rank}", B_PER_GPU, ed_dtype="bf16")
+            eng2.init_weights(seed=42)
+            eng2.seed(1234)
+            dp2 = DataParallel(eng2, 1, None)
+            n2 = max(args.steps, 64)
+            with torch.cuda.stream(eng2.stream):
+                for i in range(5):
+                    eng2.set_batch(*pool[i % len(pool)])
+                    dp2.step(True)
+                torch.cuda.synchronize()
+                evs = [ops.Event() for _ in range(n2 + 1)]
+                evs[0].record()
+                for i in range(n2):
+                    eng2.set_batch(*pool[i % len(pool)])
+                    dp2.step(True)
+                    evs[i + 1].record()
+                torch.cuda.synchronize()
+            per = sorted(evs[i].elapsed_ms(evs[i + 1]) for i in range(n2))
+            med = per[n2 // 2]
+            sec = {"metric": "piano-roll samples/sec (G+D step), batch=64 128x256 roll -- SECONDARY configuration",
+                   "dtype": "f32; frozen emotion discriminator stored in bf16 (fp32 accumulate)",
+                   "value": round(B_PER_GPU / (med * 1e-3), 1), "unit": "samples/s", "ms_per_step": round(med, 4),
+                   "steps": n2, "timing": "median of per-step hipEvent pairs",
+                   "losses": {"loss_d": round(eng2.loss_d_out[0].item(), 5), "adv": round(eng2.adv.item(), 5),
+                              "emo": round(eng2.emo.item(), 5)}}
+            del eng2, dp2
+        except Exception as e:  # the headline line must not depend on the secondary configuration
+            sec = {"error": f"{type(e).__name__}: {e}"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds)
@@ -462,12 +499,15 @@ def main():
             "metric": "piano-roll samples/sec (G+D step), batch=64 128x256 roll",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.ed_dtype == "fp32" else "f32; frozen emotion discriminator stored in bf16 (fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "cfg2: 128x256 piano-roll, batch=64 per GPU, full G+D+emotion-D step "
                                    "(1 critic update incl. gradient penalty + 1 generator update)",
                        "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
                        "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2)},
             "event_timing": event_timing, "roofline": roof, "roofline_stride2_family": roof2, "cpu_baseline": cpu,
+            "secondary_bf16_ed": sec,
             "secondary": sched,
             "losses": {"loss_d": round(loss_d, 5), "g_adv": round(adv, 5), "g_emo": round(emo, 5)},
         }

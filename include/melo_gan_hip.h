@@ -142,6 +142,39 @@ int mg_conv_tile_config(long m_rows, int N, int scatter2);
  * takes: 0 = MFMA tile kernel, 1 = thin_in_kernel, 2 / 3 = thin_out_kernel<TR2, 4 / 8>.  MG_CONV_THIN=0 disables it. */
 int mg_conv_thin_route(const float* x, long xbs, int Cin, int N, int K, int stride, int transposed);
 
+/* ---- bf16-storage / fp32-accumulate variant of the frozen emotion-discriminator branch (SECONDARY configuration) ----
+ * The branch (src/gan/train_gan.py:228-236: ED(generated) -> cross-entropy -> gradient w.r.t. the generated notes;
+ * src/emotion_discriminator/ed_model.py:24-69) has no trained parameters in the GAN step, so it can store activations and
+ * its folded weights in bf16 without touching optimiser state.  Products accumulate in fp32 (v_mfma_f32_32x32x16_bf16),
+ * epilogue arithmetic is fp32.  Never the default; bench.py reports it as a separate line.
+ *
+ * mg_epilogue_bf16: v = acc; v = v*scale[n] + shift[n]; zout[di] = bf16(v); v = act(v); v *= act'(gact, gref[di]);
+ *                   v *= gscale[n]; y = accumulate ? y + v : v (accumulate: fp32 y only).  zout / gref are bf16 tensors.
+ * mg_wb_relayout:   wb[k][n][c] = bf16(w[n*w_sn + c*w_sc + (flip ? K-1-k : k)])  -- the weight image of the kernel below
+ *                   (forward: w_sn = Cin*K, w_sc = K; stride-1 data gradient: flip = 1, w_sn = K, w_sc = Cin*K).
+ * mg_conv1d_s1_bf16: y[b,t,n] = EPI( sum_{k,c} x[b, t + k - (K-1)/2, c] * wb[k][n][c] ), K in {3,5}; x is bf16 or (x_f32)
+ *                   fp32 converted on the way into LDS; y is bf16 or (y_f32) fp32.  Needs T % 128 == 0, Cin % 32 == 0,
+ *                   N % 64 == 0 (mg_conv1d_s1_bf16_supported), dense 16-byte aligned tensors.
+ * mg_meanT_fwd_bf16 / mg_meanT_bwd_bf16: the temporal mean (ed_model.py:65) over a bf16 activation and its backward
+ *                   fused with act'(gref) * gscale, writing a bf16 gradient. */
+typedef struct mg_epilogue_bf16 {
+    const float* scale;
+    const float* shift;
+    void* zout;
+    int act;
+    const void* gref;
+    int gact;
+    const float* gscale;
+    int accumulate;
+} mg_epilogue_bf16;
+int mg_wb_relayout(const float* w, void* wb, int N, int Cc, int K, int w_sn, int w_sc, int flip, mg_stream_t stream);
+int mg_conv1d_s1_bf16_supported(int B, int T, int Cin, int N, int K);
+int mg_conv1d_s1_bf16(const void* x, int x_f32, const void* wb, void* y, int y_f32, int B, int T, int Cin, int N, int K,
+                      const mg_epilogue_bf16* epi, mg_stream_t stream);
+int mg_meanT_fwd_bf16(const void* a, float* h, int B, int T, int C, mg_stream_t stream);
+int mg_meanT_bwd_bf16(const float* dh, void* dz, const void* gref, int gact, const float* gscale, int B, int T, int C,
+                      mg_stream_t stream);
+
 /* ---- weight gradient ----
  * out[a][b][k] = sum over segments, batches, u of  S[bt,u,a] * L[bt, u*stride + k - (K-1)/2, b]
  *   S: (nb, Ts, A) "small" tensor, L: (nb, Tl, Bc) "large" tensor (zero outside [0,Tl)).

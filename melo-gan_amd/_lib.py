@@ -18,6 +18,11 @@ class Epilogue(C.Structure):
                 ("gref", vp), ("gact", i32), ("emul", vp), ("gscale", vp), ("accumulate", i32)]
 
 
+class EpilogueBf16(C.Structure):
+    _fields_ = [("scale", vp), ("shift", vp), ("zout", vp), ("act", i32), ("gref", vp), ("gact", i32), ("gscale", vp),
+                ("accumulate", i32)]
+
+
 class StageJob(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("idx", vp), ("row_bytes", i64), ("src_rows", i64), ("dst_pitch", i64)]
 
@@ -56,6 +61,11 @@ SIGNATURES = {
     "mg_linear": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_conv_tile_config": (i32, [i64, i32, i32]),
     "mg_conv_thin_route": (i32, [vp, i64, i32, i32, i32, i32, i32]),
+    "mg_wb_relayout": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mg_conv1d_s1_bf16_supported": (i32, [i32, i32, i32, i32, i32]),
+    "mg_conv1d_s1_bf16": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(EpilogueBf16), vp]),
+    "mg_meanT_fwd_bf16": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mg_meanT_bwd_bf16": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     "mg_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "mg_wgrad": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "mg_wgrad_multi": (i32, [vp, i32, i32, i32, vp, sz, vp]),

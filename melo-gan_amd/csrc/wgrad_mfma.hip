@@ -693,6 +693,8 @@ extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int s
         long tiles[MG_MAX_WGRAD_JOBS], chunks[MG_MAX_WGRAD_JOBS], total = 0;
         for (int i = 0; i < n_jobs; ++i) {
             const mg_wgrad_job& q = jobs[i];
+            MG_CHECK_ARG(q.A > 0 && q.Bc > 0 && q.Ts > 0 && q.Tl > 0 && q.nb0 > 0 && q.nb1 >= 0 && q.s0 && q.l0 && q.out,
+                         "mg_wgrad_multi: job %d: null/empty segment 0 or bad shape", i);
             const Plan pl = make_plan(q.A, q.Bc, K, q.nb0, q.nb1, q.Ts);
             tiles[i] = mg_cdiv(q.A, BA) * mg_cdiv(q.Bc, BB);
             chunks[i] = (long)(pl.nbg0 + pl.nbg1) * pl.n_ttiles;        // per tile

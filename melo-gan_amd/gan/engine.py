@@ -156,7 +156,13 @@ class FlatParams:
 class GanEngine:
     """One replica of the GAN training state on one GPU."""
 
-    def __init__(self, cfg: dict, ed_cfg: dict, device="cuda", batch_size: Optional[int] = None):
+    def __init__(self, cfg: dict, ed_cfg: dict, device="cuda", batch_size: Optional[int] = None, ed_dtype: str = "fp32"):
+        """ed_dtype: "fp32" (the product default, and what every parity claim refers to) or "bf16": the SECONDARY
+        configuration that stores the frozen emotion discriminator's activations and folded weights in bf16 and multiplies
+        them on the bf16 matrix pipe with fp32 accumulation (csrc/conv_bf16.hip); everything trained stays fp32."""
+        if ed_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"ed_dtype={ed_dtype!r}: expected 'fp32' or 'bf16'")
+        self.ed_dtype = ed_dtype
         self.cfg, self.ed_cfg = dict(cfg), dict(ed_cfg)
         self.dev = torch.device(device)
         B = self.B = int(batch_size or cfg.get("BATCH_SIZE", 32))
@@ -267,9 +273,24 @@ class GanEngine:
         self.d_p0, self.d_lat, self.d_n0, self.d_gin = z(B, 512), z(B, self.latent_dim), z(B, 512), z(B, self.in_dim)
         self.d_ez2, self.d_ez1, self.d_ex0 = z(B, h2), z(B, h1), z(B, self.num_in)
         # emotion discriminator
-        self.ed_z = [z(B, T, co) for (_, co, _) in self.ed_chans]
-        self.ed_a = [z(B, T, co) for (_, co, _) in self.ed_chans]
-        self.ed_dz = [z(B, T, co) for (_, co, _) in self.ed_chans]
+        if self.ed_dtype == "bf16":
+            if self.ed_mode != "notes":
+                raise ValueError("ed_dtype='bf16' applies to the notes-mode emotion discriminator (its convolutions)")
+            ci0 = C
+            for (_, co, k) in self.ed_chans:
+                if not ops.conv_s1_bf16_supported(B, T, ci0, co, k):
+                    raise ValueError(f"ed_dtype='bf16': layer {ci0}->{co} k={k} at T={T} is outside the bf16 kernel's shapes "
+                                     "(MAX_NOTES % 128, channels % 32 / % 64)")
+                ci0 = co
+            zb = lambda *shape: torch.zeros(*shape, device=d, dtype=torch.bfloat16)  # noqa: E731
+            # forward image [k][co][ci] and data-gradient image [k][ci][co] (taps flipped) of every folded conv weight
+            self.ed_wb_f = [zb(k, co, ci) for (ci, co, k) in self.ed_chans]
+            self.ed_wb_d = [zb(k, ci, co) for (ci, co, k) in self.ed_chans]
+        else:
+            zb = z
+        self.ed_z = [zb(B, T, co) for (_, co, _) in self.ed_chans]
+        self.ed_a = [zb(B, T, co) for (_, co, _) in self.ed_chans]
+        self.ed_dz = [zb(B, T, co) for (_, co, _) in self.ed_chans]
         hid = self.ed_cfg.get("notes_hidden", 256)
         mh = tuple(self.ed_cfg.get("mlp_hidden", (256, 128)))
         self.ed_feat_dim = hid if self.ed_mode == "notes" else self.ed_cfg.get("latent_dim", 128)
@@ -591,12 +612,26 @@ class GanEngine:
             ops.bn_fold(self.ED.p[pre + ".1.weight"], self.ED.p[pre + ".1.bias"], self.EDbuf[pre + ".1.running_mean"],
                         self.EDbuf[pre + ".1.running_var"], self.ED.p[pre + ".0.bias"], self.ed_scale[i], self.ed_shift[i], BN_EPS)
             self.ed_wt[i].copy_(self.ED.p[pre + ".0.weight"].permute(1, 0, 2))
+            if self.ed_dtype == "bf16":
+                ci, co, k = self.ed_chans[i]
+                w = self.ED.p[pre + ".0.weight"]                       # (co, ci, k)
+                ops.wb_relayout(w, self.ed_wb_f[i], co, ci, k, ci * k, k)
+                ops.wb_relayout(w, self.ed_wb_d[i], ci, co, k, k, ci * k, flip=True)
         self._ed_folded = True
 
     def _ed_fwd(self, notes: Tensor):
         """EmotionDiscriminator.forward in eval mode (ed_model.py:63-69,92-95,147-165)."""
         P = self.ED.p
-        if self.ed_mode == "notes":
+        if self.ed_mode == "notes" and self.ed_dtype == "bf16":
+            x = notes                                                  # fp32, converted on its way into LDS
+            for i in range(len(self.ed_chans)):
+                ops.conv_s1_bf16(x, self.ed_wb_f[i], self.ed_a[i], scale=self.ed_scale[i], shift=self.ed_shift[i],
+                                 zout=self.ed_z[i], act=ACT_GELU)
+                x = self.ed_a[i]
+            ops.meanT_fwd_bf16(x, self.ed_pool)
+            ops.linear_fwd(self.ed_pool, P["encoder.project.weight"], self.ed_proj, bias=P["encoder.project.bias"])
+            feat = self.ed_proj
+        elif self.ed_mode == "notes":
             x = notes
             for i in range(len(self.ed_chans)):
                 ci, co, k = self.ed_chans[i]
@@ -629,6 +664,13 @@ class GanEngine:
         ops.linear_dgrad(g, w, self.ed_dproj)
         ops.linear_dgrad(self.ed_dproj, P["encoder.project.weight"], self.ed_dpool)
         last = len(self.ed_chans) - 1
+        if self.ed_dtype == "bf16":
+            ops.meanT_bwd_bf16(self.ed_dpool, self.ed_dz[last], self.ed_z[last], ACT_GELU, self.ed_scale[last])
+            for i in range(last, 0, -1):
+                ops.conv_s1_bf16(self.ed_dz[i], self.ed_wb_d[i], self.ed_dz[i - 1], gref=self.ed_z[i - 1], gact=ACT_GELU,
+                                 gscale=self.ed_scale[i - 1])
+            ops.conv_s1_bf16(self.ed_dz[0], self.ed_wb_d[0], dnotes)   # fp32 out: the generator's gradient stays fp32
+            return
         ops.meanT_bwd(self.ed_dpool, self.ed_dz[last], gref=self.ed_z[last], gact=ACT_GELU, gscale=self.ed_scale[last])
         for i in range(last, 0, -1):
             ops.conv1d_dgrad(self.ed_dz[i], P[f"encoder.conv.{i}.net.0.weight"], self.ed_dz[i - 1], 1,

@@ -464,6 +464,85 @@ def linear_wgrad(x, dy, dw, x2=None, dy2=None, db=None, defer=False):
 
 
 # ---------------------------------------------------------------------------------------
+# bf16-storage variant of the frozen emotion-discriminator branch (secondary configuration; see include/melo_gan_hip.h)
+# ---------------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+def wb_relayout(w: Tensor, wb: Tensor, N: int, Cc: int, K: int, w_sn: int, w_sc: int, flip: bool = False) -> Tensor:
+    """wb[k][n][c] = bf16(W(n, c, flip ? K-1-k : k)), W(n,c,k) = w[n*w_sn + c*w_sc + k]: the weight image of conv_s1_bf16."""
+    _chk(w, "w")
+    _chk(wb, "wb", (K, N, Cc), BF16)
+    if w.numel() < (N - 1) * w_sn + (Cc - 1) * w_sc + K:
+        raise ValueError("wb_relayout: w smaller than its strides imply")
+    L.check(L.load().mg_wb_relayout(_p(w), _p(wb), N, Cc, K, w_sn, w_sc, 1 if flip else 0, _stream()), "mg_wb_relayout")
+    return wb
+
+
+def conv_s1_bf16_supported(B: int, T: int, Cin: int, N: int, K: int) -> bool:
+    return bool(L.load().mg_conv1d_s1_bf16_supported(B, T, Cin, N, K))
+
+
+def conv_s1_bf16(x: Tensor, wb: Tensor, y: Tensor, scale=None, shift=None, zout=None, act=ACT_NONE, gref=None,
+                 gact=ACT_NONE, gscale=None, accumulate=False) -> Tensor:
+    """Stride-1 K-tap convolution, bf16 storage / fp32 accumulate (mg_conv1d_s1_bf16).  x: (B, T, Cin) bf16 or fp32;
+    wb: (K, N, Cin) bf16 (wb_relayout); y: (B, T, N) bf16 or fp32; zout / gref: (B, T, N) bf16."""
+    if x.dtype not in (BF16, torch.float32) or y.dtype not in (BF16, torch.float32):
+        raise ValueError("conv_s1_bf16: x and y must be bf16 or fp32")
+    _chk(x, "x", dtype=x.dtype)
+    _chk(y, "y", dtype=y.dtype)
+    if x.dim() != 3 or y.dim() != 3:
+        raise ValueError("x and y must be (B, T, C)")
+    B, T, Cin = x.shape
+    K, N = wb.shape[0], wb.shape[1]
+    _chk(wb, "wb", (K, N, Cin), BF16)
+    if tuple(y.shape) != (B, T, N):
+        raise ValueError(f"y: expected {(B, T, N)}, got {tuple(y.shape)}")
+    lib = L.load()
+    if not lib.mg_conv1d_s1_bf16_supported(B, T, Cin, N, K):
+        raise ValueError(f"conv_s1_bf16: unsupported shape B={B} T={T} Cin={Cin} N={N} K={K} (T % 128, Cin % 32, N % 64)")
+    e = L.EpilogueBf16()
+    for nm, v in (("scale", scale), ("shift", shift), ("gscale", gscale)):
+        if v is not None:
+            _chk(v, nm, (N,))
+    for nm, v in (("zout", zout), ("gref", gref)):
+        if v is not None:
+            _chk(v, nm, (B, T, N), BF16)
+    if accumulate and y.dtype != torch.float32:
+        raise ValueError("conv_s1_bf16: accumulate needs an fp32 output")
+    e.scale, e.shift, e.zout, e.act = _p(scale), _p(shift), _p(zout), act
+    e.gref, e.gact, e.gscale, e.accumulate = _p(gref), gact, _p(gscale), 1 if accumulate else 0
+    def launch():
+        return lib.mg_conv1d_s1_bf16(_p(x), 1 if x.dtype == torch.float32 else 0, _p(wb), _p(y),
+                                     1 if y.dtype == torch.float32 else 0, B, T, Cin, N, K, C.byref(e), _stream())
+    with _observe(lambda: "conv_bf16_kernel<%d,%s,%s>" % (K, "true" if x.dtype == torch.float32 else "false",
+                                                          "true" if y.dtype == torch.float32 else "false"),
+                  2.0 * B * T * N * Cin * K, launch):
+        rc = launch()
+    L.check(rc, "mg_conv1d_s1_bf16")
+    return y
+
+
+def meanT_fwd_bf16(a: Tensor, h: Tensor) -> Tensor:
+    _chk(a, "a", dtype=BF16)
+    B, T, Cc = a.shape
+    _chk(h, "h", (B, Cc))
+    L.check(L.load().mg_meanT_fwd_bf16(_p(a), _p(h), B, T, Cc, _stream()), "mg_meanT_fwd_bf16")
+    return h
+
+
+def meanT_bwd_bf16(dh: Tensor, dz: Tensor, gref: Tensor, gact=ACT_NONE, gscale=None) -> Tensor:
+    _chk(dz, "dz", dtype=BF16)
+    B, T, Cc = dz.shape
+    _chk(dh, "dh", (B, Cc))
+    _chk(gref, "gref", (B, T, Cc), BF16)
+    if gscale is not None:
+        _chk(gscale, "gscale", (Cc,))
+    L.check(L.load().mg_meanT_bwd_bf16(_p(dh), _p(dz), _p(gref), gact, _p(gscale), B, T, Cc, _stream()), "mg_meanT_bwd_bf16")
+    return dz
+
+
+# ---------------------------------------------------------------------------------------
 # reductions / normalisation
 # ---------------------------------------------------------------------------------------
 def colsum(x: Tensor, out: Tensor, sumsq: Optional[Tensor] = None):

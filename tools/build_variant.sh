@@ -8,7 +8,7 @@ TAG=$1; SRC=$2; shift 2
 EXTRA=""; [ "$SRC" = conv_mfma ] && EXTRA="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $EXTRA "$@" -c $C/$SRC.hip -o tools/_build/${SRC}_$TAG.o
 OBJS=""
-for f in runtime conv_mfma conv16_mfma conv_thin linear_skinny wgrad_mfma small_kernels; do
+for f in runtime conv_mfma conv16_mfma conv_thin conv_bf16 linear_skinny wgrad_mfma small_kernels; do
   if [ "$f" = "$SRC" ]; then OBJS="$OBJS tools/_build/${SRC}_$TAG.o"; else OBJS="$OBJS $C/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o tools/_build/libmelogan_$TAG.so
