@@ -1,4 +1,7 @@
-"""Per-layer timing of the cfg2 launches via hipGraph replay (no Python launch overhead in the numbers)."""
+"""Per-layer timing of the cfg2 launches via hipGraph replay (no Python launch overhead in the numbers).  Every line takes
+the PRODUCT route of its layer: stride-2 forward / data-gradient launches run on conv16 (WQ weights) exactly where the
+engine's _conv5s2 puts them, the rest on the window GEMM / thin kernels behind ops.conv1d_* (tools/conv16_bench.py has the
+old-vs-new comparison)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, melo_gan_amd
@@ -24,18 +27,30 @@ def timeit(fn, reps=20):
 def R(*s): return torch.randn(*s, device='cuda')
 B = 64
 rows = []
+def wq_of(w, N, Cc, sn, sc):
+    wq = torch.empty(N * Cc * 5, device="cuda"); ops.wq_relayout(w, wq, N, Cc, 5, sn, sc); return wq
 def conv(tag, nb, T, Cin, Cout, K, stride):
     x = R(nb, T, Cin); w = R(Cout, Cin, K) * 0.05
     Tout = (T + 2 * (K // 2) - K) // stride + 1
     y = R(nb, Tout, Cout); dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(Cout, device='cuda')
     fl = 2.0 * nb * Tout * Cout * Cin * K
-    for name, fn in (("fwd", lambda: ops.conv1d_fwd(x, w, y, stride)), ("dgrad", lambda: ops.conv1d_dgrad(y, w, dx, stride)),
+    fwd, dgr = (lambda: ops.conv1d_fwd(x, w, y, stride)), (lambda: ops.conv1d_dgrad(y, w, dx, stride))
+    if stride == 2 and ops.conv16_supported(nb, T, Cin, Cout, False):
+        wf = wq_of(w, Cout, Cin, Cin * 5, 5); fwd = lambda: ops.conv16(x, wf, y, Cout, False)
+    if stride == 2 and ops.conv16_supported(nb, Tout, Cout, Cin, True, T):
+        wd = wq_of(w, Cin, Cout, 5, Cin * 5); dgr = lambda: ops.conv16(y, wd, dx, Cin, True, odd=(T % 2 == 1))
+    for name, fn in (("fwd", fwd), ("dgrad", dgr),
                      ("wgrad", lambda: ops.conv1d_wgrad(x, y, dw, stride, db=db))):
         us = timeit(fn); print(f"{tag:26s} {name:6s} nb={nb:3d} T={T:3d} {Cin:3d}->{Cout:3d} K={K} s={stride}: {us:7.1f} us {fl/us/1e6:6.1f} TF", flush=True)
 def convT(tag, nb, T, Cin, Cout):
     x = R(nb, T, Cin); w = R(Cin, Cout, 5) * 0.05; y = R(nb, 2 * T, Cout); dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(Cout, device='cuda')
     fl = 2.0 * nb * T * Cout * Cin * 5
-    for name, fn in (("fwd", lambda: ops.convT1d_fwd(x, w, y)), ("dgrad", lambda: ops.convT1d_dgrad(y, w, dx)),
+    fwd, dgr = (lambda: ops.convT1d_fwd(x, w, y)), (lambda: ops.convT1d_dgrad(y, w, dx))
+    if ops.conv16_supported(nb, T, Cin, Cout, True, 2 * T):
+        wf = wq_of(w, Cout, Cin, 5, Cout * 5); fwd = lambda: ops.conv16(x, wf, y, Cout, True)
+    if ops.conv16_supported(nb, 2 * T, Cout, Cin, False):
+        wd = wq_of(w, Cin, Cout, Cout * 5, 5); dgr = lambda: ops.conv16(y, wd, dx, Cin, False)
+    for name, fn in (("fwd", fwd), ("dgrad", dgr),
                      ("wgrad", lambda: ops.convT1d_wgrad(x, y, dw, db=db))):
         us = timeit(fn); print(f"{tag:26s} {name:6s} nb={nb:3d} T={T:3d} {Cin:3d}->{Cout:3d} K=5 T2: {us:7.1f} us {fl/us/1e6:6.1f} TF", flush=True)
 def lin(tag, nb, Cin, Cout):
