@@ -385,10 +385,17 @@ extern "C" int mg_wq_relayout(const float* w, float* wq, int N, int Cc, int K, i
     return MG_OK;
 }
 
-// rows per tile the planner picks: 64 unless that leaves most of the chip idle
+// Rows per tile: 64 (RT = 2: half the prologues / epilogues, weights staged half as often) unless 32-row tiles fill the
+// chip's workgroup slots more evenly.  A launch of n workgroups on 256 CUs runs ceil(n / 256) deep on the fullest CU, so
+// its balance is n / (ceil(n / 256) * 256): 384 workgroups are 1.5 per CU = 0.75, the same layer in 32-row tiles is 768
+// = 3 per CU = 1.0.  Measured (tools/conv16_bench.py, MG_CONV16_RT=1|2): the critic's 3B data-gradients conv.2 14.5 -> 12.7
+// us and conv.4 23.9 -> 20.9 us at 768 instead of 384 workgroups; every 128-workgroup layer 30-50 % faster at 256; layers at
+// 256 / 512 / >= 768 workgroups are faster or equal with 64-row tiles.
 static int pick_rt(long m_rows, int N) {
     if (const char* f = getenv("MG_CONV16_RT")) return atoi(f) == 1 ? 1 : 2;
-    return (mg_cdiv(m_rows, 64) * mg_cdiv(N, BN) >= 192) ? 2 : 1;
+    auto balance = [](long n) { return n >= 1024 ? 1.0 : (double)n / (double)(mg_cdiv(n, 256) * 256); };
+    const long n2 = mg_cdiv(m_rows, 64) * mg_cdiv(N, BN), n1 = mg_cdiv(m_rows, 32) * mg_cdiv(N, BN);
+    return balance(n1) > balance(n2) + 0.1 ? 1 : 2;
 }
 
 // 1 if mg_conv16 supports the shape (otherwise the caller uses mg_conv1d_gather / mg_conv1d_scatter2)
