@@ -15,6 +15,7 @@
 // Operand lane maps (cdna_hip_programming.md section 3): lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] and
 // B[k = 8h + j][col r], j = 0..7; D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -33,7 +34,7 @@ constexpr int BM = 128, BN = 64, BKC = 32;
 constexpr int PX = 40;                      // LDS row pitch in bf16 elements (80 bytes)
 
 template <int K, bool XF32, bool YF32>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBP p) {
+__global__ __launch_bounds__(256, K == 3 ? 3 : 2) void conv_bf16_kernel(const ConvBP p) {
     constexpr int PAD = (K - 1) / 2, XR = BM + K - 1;
     constexpr int NXP = (XR * 4 + 255) / 256;             // 16-byte pieces of the x window per thread
     constexpr int XS = XR * PX, WS = K * BN * PX;          // bf16 elements per buffer
@@ -70,8 +71,12 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBP p) {
         w_off[j] = ((k * p.N + n0 + n) * p.Cin + 8 * q);
         w_lds[j] = (k * BN + n) * PX + 8 * q;
     }
-    bf16x8 xr[NXP], wr[K];
-    auto load_chunk = [&](int c0) {
+    // Staging: global -> registers -> LDS with the registers TWO chunks ahead of the MFMAs (ring of two register sets, loop
+    // unrolled by two so that the ring index is a compile-time constant): a chunk's 12-20 MFMAs take ~400 cycles, a global
+    // load ~2000, so a one-chunk prefetch distance left every chunk waiting for memory.
+    bf16x8 xr[2][NXP], wr[2][K];
+    auto load_chunk = [&](auto ring, int c0) {
+        constexpr int G = decltype(ring)::value;
 #pragma unroll
         for (int j = 0; j < NXP; ++j) {
             bf16x8 v;
@@ -87,17 +92,18 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBP p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
             }
-            xr[j] = v;
+            xr[G][j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < K; ++j) wr[j] = *reinterpret_cast<const bf16x8*>(p.w + w_off[j] + c0);
+        for (int j = 0; j < K; ++j) wr[G][j] = *reinterpret_cast<const bf16x8*>(p.w + w_off[j] + c0);
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](auto ring, int buf) {
+        constexpr int G = decltype(ring)::value;
 #pragma unroll
         for (int j = 0; j < NXP; ++j)
-            if (x_lds[j] >= 0) *reinterpret_cast<bf16x8*>(xs + buf * XS + x_lds[j]) = xr[j];
+            if (x_lds[j] >= 0) *reinterpret_cast<bf16x8*>(xs + buf * XS + x_lds[j]) = xr[G][j];
 #pragma unroll
-        for (int j = 0; j < K; ++j) *reinterpret_cast<bf16x8*>(ws + buf * WS + w_lds[j]) = wr[j];
+        for (int j = 0; j < K; ++j) *reinterpret_cast<bf16x8*>(ws + buf * WS + w_lds[j]) = wr[G][j];
     };
     auto compute = [&](int buf) {
         const __bf16* xb = xs + buf * XS + (32 * wave + r) * PX + 8 * h;
@@ -116,74 +122,131 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvBP p) {
     };
 
     const int nchunks = p.Cin / BKC;
-    load_chunk(0);
-    store_chunk(0);
+    const std::integral_constant<int, 0> R0{};
+    const std::integral_constant<int, 1> R1{};
+    load_chunk(R0, 0);
+    if (nchunks > 1) load_chunk(R1, BKC);
+    store_chunk(R0, 0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = c + 1 < nchunks;
-        if (more) load_chunk((c + 1) * BKC);           // in flight under this chunk's MFMAs
-        compute(c & 1);
-        if (more) store_chunk((c + 1) & 1);
+    // iteration c: ring[c & 1] is free (chunk c sits in LDS[c & 1]) and takes chunk c + 2; ring[(c + 1) & 1] holds chunk c + 1
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 2 < nchunks) load_chunk(R0, (c + 2) * BKC);
+        compute(0);
+        if (c + 1 < nchunks) store_chunk(R1, 1);
+        __syncthreads();
+        if (c + 1 >= nchunks) break;
+        if (c + 3 < nchunks) load_chunk(R1, (c + 3) * BKC);
+        compute(1);
+        if (c + 2 < nchunks) store_chunk(R0, 0);
         __syncthreads();
     }
 
     // ---- epilogue (fp32 on the accumulator; every row of the tile exists) ----
+    // bf16 tensors cross the LDS on their way out / in: an accumulator lane owns ONE column and 16 rows, so storing it
+    // directly is 32 two-byte stores per thread in 64-byte runs (measured: the epilogue, not the MFMA loop, was the launch).
+    // The tile is parked in LDS as [128 rows][64 columns] (pitch 72: the two half-waves of a ds_write_b16 land on disjoint
+    // banks) and leaves as 16-byte pieces, 8 lanes per 128-byte row; gref comes in the same way.
     const mg_epilogue_bf16& E = p.e;
+    constexpr int TP = 72;
+    __bf16* tile = lds;                                    // the staging buffers are idle: every wave passed the last barrier
+    __bf16* tile2 = lds + BM * TP;                         // second parking area (pre-activation z next to the output)
+    auto lane_off = [&](int ni, int i) { return (32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h) * TP + 32 * ni + r; };
+    auto tile_to_global = [&](const __bf16* src, __bf16* dst) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + 32 * ni + r;
-        f32x16& a = acc[ni];
-        long di[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) di[i] = (long)(m0 + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h) * p.N + n;
-        if (E.scale) {
-            const float scale = E.scale[n], shift = E.shift[n];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = a[i] * scale + shift;
+        for (int j = 0; j < BM * BN / 8 / 256; ++j) {
+            const int pc = tid + 256 * j, row = pc >> 3, q = pc & 7;
+            *reinterpret_cast<bf16x8*>(dst + (long)(m0 + row) * p.N + n0 + 8 * q) = *reinterpret_cast<const bf16x8*>(src + row * TP + 8 * q);
         }
-        if (E.zout) {
+    };
+    float g[2][16];
+    if (E.gref) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) ((__bf16*)E.zout)[di[i]] = (__bf16)a[i];
+        for (int j = 0; j < BM * BN / 8 / 256; ++j) {
+            const int pc = tid + 256 * j, row = pc >> 3, q = pc & 7;
+            *reinterpret_cast<bf16x8*>(tile + row * TP + 8 * q) =
+                *reinterpret_cast<const bf16x8*>((const __bf16*)E.gref + (long)(m0 + row) * p.N + n0 + 8 * q);
         }
-        if (E.act == MG_ACT_GELU) {
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = mg_act(MG_ACT_GELU, a[i]);
-        } else if (E.act == MG_ACT_RELU) {
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = mg_act(MG_ACT_RELU, a[i]);
+            for (int i = 0; i < 16; ++i) g[ni][i] = (float)tile[lane_off(ni, i)];
+        __syncthreads();
+    }
+    if (E.scale) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float scale = E.scale[n0 + 32 * ni + r], shift = E.shift[n0 + 32 * ni + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ni][i] = acc[ni][i] * scale + shift;
         }
-        if (E.gref) {
-            float g[16];
+    }
+    if (E.zout) {           // parked now, leaves with the output behind ONE barrier (fp32 output: its own barrier)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) g[i] = (float)((const __bf16*)E.gref)[di[i]];
-            if (E.gact == MG_ACT_GELU) {
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] *= mg_act_grad(MG_ACT_GELU, g[i]);
-            } else if (E.gact == MG_ACT_RELU) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] *= mg_act_grad(MG_ACT_RELU, g[i]);
-            }
-        }
-        if (E.gscale) {
-            const float gs = E.gscale[n];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] *= gs;
-        }
+            for (int i = 0; i < 16; ++i) tile2[lane_off(ni, i)] = (__bf16)acc[ni][i];
         if (YF32) {
-            float* y = (float*)p.y;
+            __syncthreads();
+            tile_to_global(tile2, (__bf16*)E.zout);
+        }
+    }
+    if (E.act == MG_ACT_GELU) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ni][i] = mg_act(MG_ACT_GELU, acc[ni][i]);
+    } else if (E.act == MG_ACT_RELU) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ni][i] = mg_act(MG_ACT_RELU, acc[ni][i]);
+    }
+    if (E.gref) {
+        if (E.gact == MG_ACT_GELU) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ni][i] *= mg_act_grad(MG_ACT_GELU, g[ni][i]);
+        } else if (E.gact == MG_ACT_RELU) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ni][i] *= mg_act_grad(MG_ACT_RELU, g[ni][i]);
+        }
+    }
+    if (E.gscale) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const float gs = E.gscale[n0 + 32 * ni + r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ni][i] *= gs;
+        }
+    }
+    if (YF32) {
+        float* y = (float*)p.y;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const unsigned d0 = (unsigned)((m0 + 32 * wave + 4 * h) * p.N + n0 + 32 * ni + r);   // host checked: < 2^31
+            auto di = [&](int i) { return d0 + (unsigned)(((i & 3) + 8 * (i >> 2)) * p.N); };
             if (E.accumulate) {
-                float g[16];
+                float o[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) g[i] = y[di[i]];
+                for (int i = 0; i < 16; ++i) o[i] = y[di(i)];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] += g[i];
+                for (int i = 0; i < 16; ++i) acc[ni][i] += o[i];
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y[di[i]] = a[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ((__bf16*)p.y)[di[i]] = (__bf16)a[i];
+            for (int i = 0; i < 16; ++i) y[di(i)] = acc[ni][i];
         }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tile[lane_off(ni, i)] = (__bf16)acc[ni][i];
+        __syncthreads();
+        if (E.zout) tile_to_global(tile2, (__bf16*)E.zout);
+        tile_to_global(tile, (__bf16*)p.y);
     }
 }
 
