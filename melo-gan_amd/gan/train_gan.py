@@ -106,7 +106,9 @@ def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: 
     else:
         ds = GANDataset.from_split(cfg, cfg["TRAIN_SPLIT"], cfg.get("ENCODER_FEATS_TRAIN"), device)
     log(f"Train set size: {len(ds)}")
-    eng = GanEngine(cfg, ed_cfg, device, B)
+    # ED_DTYPE: bf16 = the secondary configuration (frozen emotion discriminator stored in bf16); the
+    # reference has no such key and the default is its fp32 arithmetic
+    eng = GanEngine(cfg, ed_cfg, device, B, ed_dtype=str(cfg.get("ED_DTYPE", "fp32")))
     eng.init_weights(cfg.get("SEED", 42))
     load_ed_checkpoint(eng, ed_ckpt)
     dp = DataParallel(eng, world, dist)
