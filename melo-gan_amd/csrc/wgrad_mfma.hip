@@ -106,157 +106,8 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
     };
 
     const bool fast = ((p.A & 3) == 0) && ((p.Bc & 3) == 0) && p.vec_ok && (lrows * (BB / 4) <= 256 * NL4);
-    if (fast && p.tt_log2 >= 4 && n_chunks > 0) {
-        // ---- gap-scheduled loop over two LDS buffers (same rules as conv_mfma.hip's: a wave issues in order, so
-        //      staging hides under the matrix pipe only as single LDS / VMEM instructions in the gaps between MFMAs;
-        //      VALU work costs ~17 cycles per gap and is done once per chunk, ahead of its MFMAs).  With
-        //      TT >= 16 a wave's 16 rows lie in one sequence, so every operand address is lane base + immediate. ----
-        constexpr int BUF = 0;   // (documentation only)
-        (void)BUF;
-        const int buf_floats = RT * BA + lrows * BB;
-        const int sink = 2 * buf_floats + 4 * tid;      // per-thread 16-B sink for L slots beyond the window
-        // prefetch slots: LDS float offset inside buffer 0 and chunk-invariant pieces of the global offset
-        int s_seg[NS4], s_tl[NS4], s_q[NS4];
-#pragma unroll
-        for (int j = 0; j < NS4; ++j) {
-            const int idx = tid + 256 * j;
-            const int r = idx / (BA / 4);
-            s_q[j] = idx - r * (BA / 4);
-            s_seg[j] = r >> p.tt_log2;
-            s_tl[j] = r & (TT - 1);
-        }
-        int l_seg[NL4], l_rr[NL4], l_q[NL4], l_lds[NL4], l_ldd[NL4];
-#pragma unroll
-        for (int j = 0; j < NL4; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx / (BB / 4);
-            l_q[j] = idx - row * (BB / 4);
-            l_seg[j] = (TB == 1) ? 0 : row / R;
-            l_rr[j] = row - l_seg[j] * R;
-            const bool live = row < lrows;
-            l_lds[j] = live ? RT * BA + 4 * idx : sink;
-            l_ldd[j] = live ? buf_floats : 0;
-            if (!live) l_seg[j] = 1 << 20;               // never a valid batch
-        }
-        f32x4 sr[NS4], lr[NL4];
-        unsigned so[NS4], lo[NL4];       // byte offsets of the chunk being fetched (0x80000000 = reads as zero)
-        __amdgpu_buffer_rsrc_t srs, lrs;
-        // chunk-invariant part of every slot's byte offset (batch 0, time 0 of the chunk's window); the chunk adds one
-        // wave-uniform term and three compares per slot -- the only VALU work per chunk
-        unsigned s_base[NS4], l_base[NL4];
-#pragma unroll
-        for (int j = 0; j < NS4; ++j) {
-            s_base[j] = (unsigned)((((long)s_seg[j] * p.Ts + s_tl[j]) * p.A + a0 + 4 * s_q[j]) * 4);
-            if (a0 + 4 * s_q[j] >= p.A) s_seg[j] = 1 << 20;          // never valid
-        }
-#pragma unroll
-        for (int j = 0; j < NL4; ++j) {
-            l_base[j] = (unsigned)((((long)l_seg[j] * p.Tl + l_rr[j]) * p.Bc + b0 + 4 * l_q[j]) * 4);
-            if (b0 + 4 * l_q[j] >= p.Bc) l_seg[j] = 1 << 20;
-        }
-        auto chunk_addr = [&](int c) {
-            const int g = g_begin + c / p.n_ttiles, tt = c - (c / p.n_ttiles) * p.n_ttiles;
-            const int seg_id = g < p.nbg0 ? 0 : 1;
-            const int bg = seg_id ? g - p.nbg0 : g;
-            const int nb = p.nb[seg_id];
-            const int bb0 = bg * TB, t0 = tt * TT, tl0 = t0 * S - PAD;
-            srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(seg_id ? p.s[1] : p.s[0]), 0,
-                                                    (int)((long)nb * p.Ts * p.A * 4), 0x00020000);
-            lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(seg_id ? p.l[1] : p.l[0]), 0,
-                                                    (int)((long)nb * p.Tl * p.Bc * 4), 0x00020000);
-            const unsigned s_add = (unsigned)((((long)bb0 * p.Ts + t0) * p.A) * 4);
-            const unsigned l_add = (unsigned)((((long)bb0 * p.Tl + tl0) * p.Bc) * 4);     // tl0 < 0 wraps; the sum is right
-            const int nbv = nb - bb0, tsv = p.Ts - t0;
-#pragma unroll
-            for (int j = 0; j < NS4; ++j)
-                so[j] = (s_seg[j] < nbv && s_tl[j] < tsv) ? s_base[j] + s_add : 0x80000000u;
-#pragma unroll
-            for (int j = 0; j < NL4; ++j) {
-                const int t = tl0 + l_rr[j];
-                lo[j] = (l_seg[j] < nbv && t >= 0 && t < p.Tl) ? l_base[j] + l_add : 0x80000000u;
-            }
-        };
-        auto bload = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned off) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-            return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-        };
-        auto lds4 = [&](int off) { return reinterpret_cast<f32x4*>(__builtin_assume_aligned(smem + off, 16)); };
-        auto store_s = [&](int j, int buf) { *lds4(4 * (tid + 256 * j) + (buf ? buf_floats : 0)) = sr[j]; };
-        auto store_l = [&](int j, int buf) { *lds4(l_lds[j] + (buf ? l_ldd[j] : 0)) = lr[j]; };
-
-        // this lane's operand bases inside a buffer: rows wave*16 + 2*r2 + h of the chunk
-        const int r0 = wave * (RT / 4) + h;
-        const int abase = r0 * BA + (lane & 31);
-        const int lbase = RT * BA + ((r0 >> p.tt_log2) * R + (r0 & (TT - 1)) * S) * BB + (lane & 31);
-        constexpr int NR2 = RT / 8;                 // MFMA row-pairs per wave per chunk
-        constexpr int NOPS = 2 * (NS4 + NL4);       // store / reload of every prefetch slot
-        constexpr int NGAP = (NR2 - 1) * K;         // gaps ahead of the barrier
-        typedef float f32x8 __attribute__((ext_vector_type(8)));
-        f32x8 fr[2];        // operand sets of two consecutive row pairs: [0..K-1] = the K taps of L, [7] = S
-        auto frag_read = [&](int boff, int r2) {
-            f32x8 v;
-            v[7] = smem[boff + abase + 2 * r2 * BA];
-#pragma unroll
-            for (int k = 0; k < K; ++k) v[k] = smem[boff + lbase + (2 * r2 * S + k) * BB];
-            return v;
-        };
-        auto chunk = [&](auto parity, int c) {
-            constexpr int P = decltype(parity)::value;
-            const int cur = P ? buf_floats : 0, oth = buf_floats - cur;
-            chunk_addr(min(c + 2, n_chunks - 1));    // addresses of the chunk the reloads below fetch
-#pragma unroll
-            for (int m = 0; m < NR2 * K; ++m) {
-                const int r2 = m / K, k = m % K;
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[r2 & 1][7], fr[r2 & 1][k], acc[k], 0, 0, 0);
-                if (k == 0) {
-                    if (r2 == NR2 - 1) __syncthreads();           // other buffer complete, this one read out
-                    if (r2 + 1 < NR2) fr[(r2 + 1) & 1] = frag_read(cur, r2 + 1);
-                    else fr[0] = frag_read(oth, 0);
-                }
-                if (r2 < NR2 - 1) {
-                    const int gap = r2 * K + k;
-#pragma unroll
-                    for (int o = 0; o < NOPS; ++o) {
-                        if (o * NGAP / NOPS != gap) continue;
-                        const int j = o / 2;
-                        if (j < NS4) {
-                            if (o % 2 == 0) store_s(j, 1 - P);
-                            else sr[j] = bload(srs, so[j]);
-                        } else {
-                            if (o % 2 == 0) store_l(j - NS4, 1 - P);
-                            else lr[j - NS4] = bload(lrs, lo[j - NS4]);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto load_all = [&]() {
-#pragma unroll
-            for (int j = 0; j < NS4; ++j) sr[j] = bload(srs, so[j]);
-#pragma unroll
-            for (int j = 0; j < NL4; ++j) lr[j] = bload(lrs, lo[j]);
-        };
-        chunk_addr(0);
-        load_all();
-#pragma unroll
-        for (int j = 0; j < NS4; ++j) store_s(j, 0);
-#pragma unroll
-        for (int j = 0; j < NL4; ++j) store_l(j, 0);
-        if (n_chunks > 1) {              // (a single chunk -- the Linear layers' 64-row batches -- has nothing to prefetch)
-            chunk_addr(1);
-            load_all();
-        }
-        __syncthreads();
-        fr[0] = frag_read(0, 0);
-        MG_STAMP(1);
-        for (int c = 0;;) {
-            chunk(std::integral_constant<int, 0>{}, c);
-            if (++c >= n_chunks) break;
-            chunk(std::integral_constant<int, 1>{}, c);
-            if (++c >= n_chunks) break;
-        }
-    } else if (fast) {
+    // (aligned tensors with sequences of >= 16 positions never get here: wgrad16_body, below, serves them)
+    if (fast) {
         // short sequences (TT < 16: a wave's rows straddle sequences): the pre-gap-scheduling loop.  The next chunk's
         // S rows and L window are fetched with raw-buffer float4 loads (out-of-range slots return 0 in hardware) while
         // the current chunk is multiplied; single LDS buffer, two barriers per chunk
@@ -395,6 +246,204 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, const int bx, const 
     MG_STAMP(3);
 }
 
+// ---- the same tile on v_mfma_f32_16x16x4_f32 (round 2) --------------------------------------------------------------
+// wgrad_body's four waves split the ROWS of a chunk and each keep the whole 32x32xK tile: the tile has to be added across
+// the waves through LDS at the end (3.4 us per workgroup, 50-84 KB of LDS) and every wave reads both operands for all 32x32
+// outputs.  Here the four waves split the TILE: wave (wa, wb) owns the 16(a) x 16(b) x K sub-tile over ALL rows of every
+// chunk -- K accumulators of 4 registers, no cross-wave sum; the epilogue only re-orders the tile through LDS into dW's
+// layout for coalesced stores.  Per 4-row block a wave reads S once and the L window K times (1 + K ds_read_b32 for K MFMAs,
+// lane (i, kq) = column i, row 4g + kq): MFMA operand maps A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15].  LDS rows are
+// padded so that the two row pairs of a half-wave hit disjoint banks: S rows one apart -> pitch 48 floats, L window rows
+// S apart -> pitch 40 (stride 2) / 48 (stride 1).  Same staging, same gap-scheduling rules as wgrad_body; used when that
+// body's gap-scheduled path applies (aligned tensors, sequences of >= 16 positions), otherwise wgrad_body runs.
+constexpr int W16_SP = 48;
+template <int S> struct W16LP { static constexpr int value = S == 2 ? 40 : 48; };
+
+template <int S, int K>
+__device__ __forceinline__ bool wgrad16_applies(const WgradP& p) {
+    constexpr int RMAX = (RT - 1) * S + K;
+    constexpr int NL4 = (RMAX * (BB / 4) + 255) / 256 + 1;
+    const int TT = 1 << p.tt_log2, TB = RT >> p.tt_log2, R = (TT - 1) * S + K;
+    return ((p.A & 3) == 0) && ((p.Bc & 3) == 0) && p.vec_ok && (TB * R * (BB / 4) <= 256 * NL4) && p.tt_log2 >= 4;
+}
+
+template <int S, int K>
+__device__ __forceinline__ void wgrad16_body(const WgradP& p, const int bx, const int by, const int bz) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int RMAX = (RT - 1) * S + K;
+    constexpr int NS4 = RT * (BA / 4) / 256;
+    constexpr int NL4 = (RMAX * (BB / 4) + 255) / 256 + 1;
+    constexpr int SP = W16_SP, LP = W16LP<S>::value;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4, wa = wave & 1, wb = wave >> 1;
+    const int TT = 1 << p.tt_log2, TB = RT >> p.tt_log2;
+    const int R = (TT - 1) * S + K;
+    const int lrows = TB * R;
+    const int a0 = bx * BA, b0 = by * BB;
+    const int g_begin = bz * p.bps, g_end = min(g_begin + p.bps, p.n_bgroups);
+    const int n_chunks = (g_end - g_begin) * p.n_ttiles;
+    float* out = p.part ? p.part + (long)bz * p.slab : p.out;
+
+    f32x4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (n_chunks > 0) {
+        const int buf_floats = RT * SP + lrows * LP;
+        const int sink = 2 * buf_floats + 4 * tid;
+        // Staging slots.  Slot j of a thread is the float4 (row idx/8, column quad idx%8) of the S rows / the L window.  Its
+        // byte offset has a part fixed for the whole workgroup (s_base / l_base, relative to the chunk's first batch row
+        // and, for the L window, to time t0*S - PAD of that row) and a wave-uniform part per chunk.  Nothing is compared per
+        // chunk: the chunk's buffer descriptor starts at its first batch row and covers exactly the batch rows that exist
+        // (a chunk of long sequences, TB = 1: ONE sequence), so window rows before time 0 (negative offset = huge unsigned),
+        // past the sequence end and batch rows past the segment's end are out of range and read as zero in hardware.
+        // Chunks of several short sequences (TB > 1) always start at time 0 (one time tile per sequence), so there the
+        // time range check is static and folded into the slot.  (Round 1 recomputed three compares per slot and two
+        // integer divisions per chunk ahead of the chunk's first MFMA: 7 us of the critic's 72-us launch.)
+        constexpr unsigned DEAD = 0xC0000000u;          // stays out of range whatever a chunk adds (< 2^30, host checked)
+        int s_lds[NS4];
+        unsigned s_base[NS4];
+#pragma unroll
+        for (int j = 0; j < NS4; ++j) {
+            const int idx = tid + 256 * j, r = idx / (BA / 4), q = idx - r * (BA / 4);
+            const int seg = r >> p.tt_log2, tl = r & (TT - 1);
+            s_lds[j] = r * SP + 4 * q;
+            s_base[j] = (unsigned)((((long)seg * p.Ts + tl) * p.A + a0 + 4 * q) * 4);
+            if (a0 + 4 * q >= p.A || (TB > 1 && tl >= p.Ts)) s_base[j] = DEAD;
+        }
+        int l_lds[NL4], l_ldd[NL4];
+        unsigned l_base[NL4];
+#pragma unroll
+        for (int j = 0; j < NL4; ++j) {
+            const int idx = tid + 256 * j, row = idx / (BB / 4), q = idx - row * (BB / 4);
+            const int seg = (TB == 1) ? 0 : row / R, rr = row - seg * R;
+            const bool live = row < lrows;
+            l_lds[j] = live ? RT * SP + row * LP + 4 * q : sink;
+            l_ldd[j] = live ? buf_floats : 0;
+            l_base[j] = (unsigned)(int)((((long)seg * p.Tl + rr - PAD) * p.Bc + b0 + 4 * q) * 4);
+            if (!live || b0 + 4 * q >= p.Bc || (TB > 1 && (rr < PAD || rr - PAD >= p.Tl))) l_base[j] = DEAD;
+        }
+        f32x4 sr[NS4], lr[NL4];
+        __amdgpu_buffer_rsrc_t srs, lrs;
+        unsigned s_add = 0, l_add = 0;   // the chunk's wave-uniform offset parts (0 when TB > 1)
+        int nc = 0, ng = g_begin, ntt = 0;              // the chunk the next loads fetch: index, batch group, time tile
+        auto chunk_desc = [&]() {
+            const int seg_id = ng < p.nbg0 ? 0 : 1;
+            const int bg = seg_id ? ng - p.nbg0 : ng;
+            const int bb0 = bg * TB;
+            const int nbv = min(TB, p.nb[seg_id] - bb0);
+            srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((seg_id ? p.s[1] : p.s[0]) + (long)bb0 * p.Ts * p.A), 0,
+                                                    nbv * p.Ts * p.A * 4, 0x00020000);
+            lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((seg_id ? p.l[1] : p.l[0]) + (long)bb0 * p.Tl * p.Bc), 0,
+                                                    nbv * p.Tl * p.Bc * 4, 0x00020000);
+            const int t0 = ntt << p.tt_log2;
+            s_add = (unsigned)(t0 * p.A * 4);
+            l_add = (unsigned)(t0 * S * p.Bc * 4);
+        };
+        auto chunk_next = [&]() {        // step to the next chunk unless already at the last one (which is then re-staged)
+            if (nc + 1 < n_chunks) {
+                ++nc;
+                if (++ntt == p.n_ttiles) { ntt = 0; ++ng; }
+            }
+            chunk_desc();
+        };
+        auto bload = [&](const __amdgpu_buffer_rsrc_t& rsrc, unsigned off) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        };
+        auto lds4 = [&](int off) { return reinterpret_cast<f32x4*>(__builtin_assume_aligned(smem + off, 16)); };
+        auto store_s = [&](int j, int buf) { *lds4(s_lds[j] + (buf ? buf_floats : 0)) = sr[j]; };
+        auto store_l = [&](int j, int buf) { *lds4(l_lds[j] + (buf ? l_ldd[j] : 0)) = lr[j]; };
+
+        // operand addresses: row block g covers chunk rows 4g .. 4g+3 (one per kq); block g's L window starts at window row
+        // (4g >> tt_log2) * R + (4g & (TT-1)) * S -- a wave-uniform term per block, the lane adds kq * S rows and its column
+        const int abase = kq * SP + 16 * wa + li;
+        const int lbase = RT * SP + kq * S * LP + 16 * wb + li;
+        constexpr int NG = RT / 4;                  // row blocks per chunk
+        constexpr int NOPS = 2 * (NS4 + NL4);
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        f32x8 fr[2];        // operand sets of two consecutive row blocks: [0..K-1] = the K taps of L, [7] = S
+        auto block_off = [&](int g) { return (((4 * g) >> p.tt_log2) * R + ((4 * g) & (TT - 1)) * S) * LP; };
+        auto read_a = [&](int boff, int g, f32x8& v) { v[7] = smem[boff + abase + 4 * g * SP]; };
+        auto read_b = [&](int boff, int g, int k, f32x8& v) { v[k] = smem[boff + lbase + block_off(g) + k * LP]; };
+        auto chunk = [&](auto parity, int c) {
+            constexpr int P = decltype(parity)::value;
+            const int cur = P ? buf_floats : 0, oth = buf_floats - cur;
+            chunk_next();                            // descriptors of the chunk the reloads below fetch: c + 2
+#pragma unroll
+            for (int m = 0; m < NG * K; ++m) {
+                const int g = m / K, k = m % K;
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr[g & 1][7], fr[g & 1][k], acc[k], 0, 0, 0);
+                // gap behind MFMA (g, k): operand k (and the S value with k == 0) of the next row block -- of the next chunk's
+                // first block, from the other buffer, behind the barrier in the last block -- and one staging op
+                const int gn = g + 1 < NG ? g + 1 : 0, bo = g + 1 < NG ? cur : oth;
+                if (g + 1 == NG && k == 0) __syncthreads();       // other buffer complete, this one read out
+                if (k == 0) read_a(bo, gn, fr[(g + 1) & 1]);
+                read_b(bo, gn, k, fr[(g + 1) & 1]);
+                if (g + 1 < NG && k == K - 1) {
+#pragma unroll
+                    for (int o = 0; o < NOPS; ++o) {
+                        if (o * (NG - 1) / NOPS != g) continue;
+                        const int j = o / 2;
+                        if (j < NS4) {
+                            if (o % 2 == 0) store_s(j, 1 - P);
+                            else sr[j] = bload(srs, s_base[j] + s_add);
+                        } else {
+                            if (o % 2 == 0) store_l(j - NS4, 1 - P);
+                            else lr[j - NS4] = bload(lrs, l_base[j - NS4] + l_add);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto load_all = [&]() {
+#pragma unroll
+            for (int j = 0; j < NS4; ++j) sr[j] = bload(srs, s_base[j] + s_add);
+#pragma unroll
+            for (int j = 0; j < NL4; ++j) lr[j] = bload(lrs, l_base[j] + l_add);
+        };
+        chunk_desc();
+        load_all();
+#pragma unroll
+        for (int j = 0; j < NS4; ++j) store_s(j, 0);
+#pragma unroll
+        for (int j = 0; j < NL4; ++j) store_l(j, 0);
+        if (n_chunks > 1) {
+            chunk_next();
+            load_all();
+        }
+        __syncthreads();
+        read_a(0, 0, fr[0]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) read_b(0, 0, k, fr[0]);
+        for (int c = 0;;) {
+            chunk(std::integral_constant<int, 0>{}, c);
+            if (++c >= n_chunks) break;
+            chunk(std::integral_constant<int, 1>{}, c);
+            if (++c >= n_chunks) break;
+        }
+    }
+
+    // ---- epilogue: the tile through LDS into dW's layout (row a = K*32 contiguous floats), coalesced stores ----
+    // D layout of the 16x16 MFMA: column (b) = lane & 15, rows (a) = 4 * (lane >> 4) + r
+    __syncthreads();
+    constexpr int PE = K * 32 + 1;
+    float* red = smem;                                   // [32][K*32 (+1)]
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(16 * wa + 4 * kq + r) * PE + (16 * wb + li) * K + k] = acc[k][r];
+    __syncthreads();
+    const int nb_valid = min(32, p.Bc - b0) * K;         // floats per row of this tile that exist in `out`
+#pragma unroll 4
+    for (int idx = tid; idx < 32 * K * 32; idx += 256) {
+        const int ar = idx / (K * 32), j = idx - ar * (K * 32);
+        if (a0 + ar < p.A && j < nb_valid) out[((long)(a0 + ar) * p.Bc + b0) * K + j] = red[ar * PE + j];
+    }
+}
+
 // The bias gradient -- column sums of S (Conv1d / Linear: bias_from 1) or of L (ConvTranspose1d: 2) over the segments
 // that carry one -- is the work of EXTRA workgroups of the same launch, one per (slice, 32-column block): a streaming
 // sum of the slice's rows (a few hundred rows x 128 B, ~1-2 us) into the slab's bias entries, which the slab reduction
@@ -456,7 +505,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
     const int id = (int)blockIdx.x - nbias, gxy = p.gx * p.gy;
     if (id >= 0) {
         const int bz = id / gxy, r = id - bz * gxy;
-        wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
+        if (wgrad16_applies<S, K>(p)) wgrad16_body<S, K>(p, r % p.gx, r / p.gx, bz);
+        else wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
     } else {
         const int k = (int)blockIdx.x;
         wgrad_bias_body(p, k % ncb, k / ncb);
@@ -481,7 +531,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgradJobs J) 
     const int id = b - nbias, gxy = p.gx * p.gy;
     if (id >= 0) {
         const int bz = id / gxy, r = id - bz * gxy;
-        wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
+        if (wgrad16_applies<S, K>(p)) wgrad16_body<S, K>(p, r % p.gx, r / p.gx, bz);
+        else wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
     } else {
         wgrad_bias_body(p, b % ncb, b / ncb);
     }
@@ -634,10 +685,20 @@ int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, cons
     size_t lds_floats = 2 * ((size_t)RT * BA + (size_t)pl.TB * R * BB) + 256 * 4;   // two buffers + the staging sink
     const size_t epi_floats = (size_t)4 * (K > 3 ? 3 : K) * 32 * 33;     // the cross-wave reduction (passes of <= 3 taps) reuses the buffers
     if (lds_floats < epi_floats) lds_floats = epi_floats;
-    lds = lds_floats * sizeof(float);
     auto ok = [](const float* q, long elems) { return q == nullptr || (((((uintptr_t)q) & 15) == 0) && elems * 4 < (1L << 31)); };
     p.vec_ok = ok(s0, (long)nb0 * Ts * A) && ok(l0, (long)nb0 * Tl * Bc) && ok(nb1 ? s1 : nullptr, (long)nb1 * Ts * A) &&
-               ok(nb1 ? l1 : nullptr, (long)nb1 * Tl * Bc);
+               ok(nb1 ? l1 : nullptr, (long)nb1 * Tl * Bc) && (long)Tl * Bc * 4 < (1L << 30) && (long)Ts * A * 4 < (1L << 30);
+    // the 16x16x4 body (same condition as wgrad16_applies): padded images (rows at pitch 48 / 40-48 floats), re-ordering tile
+    {
+        const int rmax = (RT - 1) * stride + K, nl4 = (rmax * (BB / 4) + 255) / 256 + 1;
+        if ((A & 3) == 0 && (Bc & 3) == 0 && p.vec_ok && pl.TB * R * (BB / 4) <= 256 * nl4 && pl.tt_log2 >= 4) {
+            const size_t lp16 = stride == 2 ? 40 : 48;
+            lds_floats = 2 * ((size_t)RT * W16_SP + (size_t)pl.TB * R * lp16) + 256 * 4;
+            const size_t epi16 = (size_t)32 * (K * 32 + 1);
+            if (lds_floats < epi16) lds_floats = epi16;
+        }
+    }
+    lds = lds_floats * sizeof(float);
     p.gx = (int)mg_cdiv(A, BA); p.gy = (int)mg_cdiv(Bc, BB); p.gz = pl.nsplit;
     const int nbias = bias_from ? pl.nsplit * (int)mg_cdiv(bias_from == 1 ? A : Bc, 32) : 0;
     grid = dim3((unsigned)(p.gx * p.gy * p.gz + nbias));      // 1-D: the bias workgroups, then the tile workgroups
