@@ -467,6 +467,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
     MG_STAMP(3);
     const mg_epilogue& E = p.e;
     const long slab = (long)p.B * p.Tout * p.N;
+    // LIN: the tile lies wholly inside the tensor and its rows are consecutive rows of a dense (B*Tout, N) output (gather
+    // form; a tile of several sequences covers them whole) -- every row exists and element r sits a fixed number of rows
+    // below the lane's first one: no per-element index arithmetic, no predicated stores.  Every emotion-discriminator launch.
+    const bool lin_tile = !TR2 && p.ybs == (long)p.Tout * p.N && b0 + TB <= p.B && t0 + TT <= p.Tm && (TB == 1 || TT == p.Tm);
+    auto epilogue_pass = [&](auto lin_tag) {
+    constexpr bool LIN = decltype(lin_tag)::value;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
         const int n = n0 + wn * 32 * TN + ni * 32 + (lane & 31);
@@ -477,7 +483,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             for (int ph = 0; ph < NPH; ++ph) {
                 f32x16& a = acc[ph][mi][ni];
                 // dense / strided output index of accumulator element r; false if the row is outside the tensor
+                const unsigned lin0 = (unsigned)(((b0 * p.Tm + t0) + wm * 32 * TM + mi * 32 + 4 * (lane >> 5)) * p.N + n);
                 auto index = [&](int r, unsigned& di, unsigned& yi) -> bool {
+                    if (LIN) {
+                        di = yi = lin0 + (unsigned)(((r & 3) + 8 * (r >> 2)) * p.N);
+                        return true;
+                    }
                     const int im = wm * 32 * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int seg = im >> p.tt_log2, tl = im & (TT - 1);
                     const int b = b0 + seg, t = t0 + tl;
@@ -569,6 +580,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             }
         }
     }
+    };
+    if (lin_tile) epilogue_pass(std::true_type{});
+    else epilogue_pass(std::false_type{});
     MG_STAMP(4);
 #ifdef MG_STAMPS
     if (threadIdx.x == 0 && mg_stamp_buf)    // shader-clock cycles over the workgroup's life: slot 15
