@@ -284,6 +284,7 @@ __device__ __forceinline__ void wgrad16_body(const WgradP& p, const int bx, cons
     const int g_begin = bz * p.bps, g_end = min(g_begin + p.bps, p.n_bgroups);
     const int n_chunks = (g_end - g_begin) * p.n_ttiles;
     float* out = p.part ? p.part + (long)bz * p.slab : p.out;
+    MG_STAMP(0);
 
     f32x4 acc[K];
 #pragma unroll
@@ -418,6 +419,7 @@ __device__ __forceinline__ void wgrad16_body(const WgradP& p, const int bx, cons
         read_a(0, 0, fr[0]);
 #pragma unroll
         for (int k = 0; k < K; ++k) read_b(0, 0, k, fr[0]);
+        MG_STAMP(1);
         for (int c = 0;;) {
             chunk(std::integral_constant<int, 0>{}, c);
             if (++c >= n_chunks) break;
@@ -425,6 +427,7 @@ __device__ __forceinline__ void wgrad16_body(const WgradP& p, const int bx, cons
             if (++c >= n_chunks) break;
         }
     }
+    MG_STAMP(2);
 
     // ---- epilogue: the tile through LDS into dW's layout (row a = K*32 contiguous floats), coalesced stores ----
     // D layout of the 16x16 MFMA: column (b) = lane & 15, rows (a) = 4 * (lane >> 4) + r
@@ -442,6 +445,7 @@ __device__ __forceinline__ void wgrad16_body(const WgradP& p, const int bx, cons
         const int ar = idx / (K * 32), j = idx - ar * (K * 32);
         if (a0 + ar < p.A && j < nb_valid) out[((long)(a0 + ar) * p.Bc + b0) * K + j] = red[ar * PE + j];
     }
+    MG_STAMP(3);
 }
 
 // The bias gradient -- column sums of S (Conv1d / Linear: bias_from 1) or of L (ConvTranspose1d: 2) over the segments
@@ -501,14 +505,13 @@ __device__ __forceinline__ void wgrad_bias_body(const WgradP& p, const int cb, c
 
 template <int S, int K>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
-    const int ncb = p.bias_from ? ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5 : 0, nbias = ncb * p.gz;
-    const int id = (int)blockIdx.x - nbias, gxy = p.gx * p.gy;
-    if (id >= 0) {
+    const int id = (int)blockIdx.x, gxy = p.gx * p.gy, ntile = gxy * p.gz;
+    if (id < ntile) {
         const int bz = id / gxy, r = id - bz * gxy;
         if (wgrad16_applies<S, K>(p)) wgrad16_body<S, K>(p, r % p.gx, r / p.gx, bz);
         else wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
-    } else {
-        const int k = (int)blockIdx.x;
+    } else {                     // the bias workgroups come last: they fill the slots the first finished tiles leave
+        const int ncb = ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5, k = id - ntile;
         wgrad_bias_body(p, k % ncb, k / ncb);
     }
 }
@@ -518,22 +521,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
 // once.  Workgroups are numbered job by job; first[j] is job j's first workgroup.
 struct WgradJobs {
     WgradP p[MG_MAX_WGRAD_JOBS];
-    int first[MG_MAX_WGRAD_JOBS + 1];
-    int n;
+    int first[MG_MAX_WGRAD_JOBS + 1];      // tile workgroups, job by job
+    int bfirst[MG_MAX_WGRAD_JOBS + 1];     // then every job's bias workgroups (short: they fill the slots the first
+    int n;                                 // finished tiles leave; ahead of the tiles they delayed a third of them by 5 us)
 };
 template <int S, int K>
 __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgradJobs J) {
+    const int bid = (int)blockIdx.x;
+    const bool tile = bid < J.first[J.n];
+    const int* first = tile ? J.first : J.bfirst;
     int j = 0;
-    while (j + 1 < J.n && (int)blockIdx.x >= J.first[j + 1]) ++j;       // uniform
-    const int b = (int)blockIdx.x - J.first[j];
+    while (j + 1 < J.n && bid >= first[j + 1]) ++j;       // uniform
+    const int b = bid - first[j];
     const WgradP& p = J.p[j];          // a reference: the by-value copy landed in scratch memory once two bodies used it
-    const int ncb = p.bias_from ? ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5 : 0, nbias = ncb * p.gz;
-    const int id = b - nbias, gxy = p.gx * p.gy;
-    if (id >= 0) {
-        const int bz = id / gxy, r = id - bz * gxy;
+    if (tile) {
+        const int gxy = p.gx * p.gy, bz = b / gxy, r = b - bz * gxy;
         if (wgrad16_applies<S, K>(p)) wgrad16_body<S, K>(p, r % p.gx, r / p.gx, bz);
         else wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
     } else {
+        const int ncb = ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5;
         wgrad_bias_body(p, b % ncb, b / ncb);
     }
 }
@@ -701,7 +707,7 @@ int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, cons
     lds = lds_floats * sizeof(float);
     p.gx = (int)mg_cdiv(A, BA); p.gy = (int)mg_cdiv(Bc, BB); p.gz = pl.nsplit;
     const int nbias = bias_from ? pl.nsplit * (int)mg_cdiv(bias_from == 1 ? A : Bc, 32) : 0;
-    grid = dim3((unsigned)(p.gx * p.gy * p.gz + nbias));      // 1-D: the bias workgroups, then the tile workgroups
+    grid = dim3((unsigned)(p.gx * p.gy * p.gz + nbias));      // 1-D: the tile workgroups, then the bias workgroups
     return MG_OK;
 }
 }  // namespace
@@ -795,10 +801,18 @@ extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int s
             rblocks += (int)mg_cdiv(J.p[i].slab, 64);
         }
         lds_max = lds > lds_max ? lds : lds_max;
+        const int ntile = J.p[i].gx * J.p[i].gy * J.p[i].gz;
         J.first[i] = nblocks;
-        nblocks += (int)grid.x;
+        nblocks += ntile;
+        J.bfirst[i] = (int)grid.x - ntile;            // count for now; turned into a start below
     }
     J.first[n_jobs] = nblocks;
+    for (int i = 0; i < n_jobs; ++i) {
+        const int nb = J.bfirst[i];
+        J.bfirst[i] = nblocks;
+        nblocks += nb;
+    }
+    J.bfirst[n_jobs] = nblocks;
     J.n = n_jobs;
     Rj.first[Rj.njobs] = rblocks;
     hipStream_t st = (hipStream_t)stream;
