@@ -73,6 +73,10 @@ class DataParallel:
         engine.world_size = self.world
         self._pending = []
         self._prepared = False
+        self._prev_g = False                                        # was the previous batch a generator step (split flow)
+        # split | ingraph | none.  Default: the split flow for the fp32 engine; the bf16-stored emotion branch is a third as
+        # long and the three extra graph launches cost more than hiding it returns (0.831 -> 0.872 ms)
+        self._ed_flow = os.environ.get("MELO_ED_FLOW") or ("split" if getattr(engine, "ed_dtype", "fp32") == "fp32" else "none")
 
     def _flat_state(self):
         e = self.engine
@@ -179,6 +183,27 @@ class DataParallel:
         docstring)."""
         e = self.engine
         if not self.active:
+            side = getattr(e, "ed_side", None)
+            back_to_back, self._prev_g = self._prev_g and g_step, g_step
+            if back_to_back and use_graph and side is not None and self._ed_flow == "split":
+                # The split flow: the frozen emotion discriminator's branch (a third of the step's MFMA work; needs only the
+                # generated batch, is needed only where the generator's backward starts) runs as its OWN graph on a side
+                # stream beside the critic step, whose ~50 launches are mostly small dependent kernels that leave the matrix
+                # pipes idle.  Four graphs per batch: [draw + 2B-row generator pass] -> fork -> side: [emotion branch] beside
+                # main: [critic step + critic pass over the generated batch] -> join -> [generator backward + update].
+                # Only when generator steps follow each other (the host is then a whole step ahead of the GPU): measured
+                # 0.959 -> 0.929 ms/batch at 1 critic : 1 generator update, but 0.474 -> 0.503 at the reference's 5 : 1
+                # (DESIGN.md section 6, Streams).
+                import torch
+                cur = torch.cuda.current_stream()
+                e.run("dg_forward_rng", True)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    e.run("g_ed_branch", True)
+                e.run("d_step_g_critic_front", True)
+                cur.wait_stream(side)
+                e.run("g_finish", True)
+                return
             # one graph per batch: the critic step alone, or critic + generator step with ONE 2B-row generator pass
             e.run("dg_step_rng" if g_step else "d_step_rng", use_graph)
             return

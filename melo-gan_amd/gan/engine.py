@@ -24,6 +24,7 @@ the oracle's draws and production runs fill the same buffers from the device RNG
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, Optional, Sequence
 
@@ -309,6 +310,8 @@ class GanEngine:
         self._graphs = {}
         # hipGraph capture is illegal on the null stream: every step runs on this side stream
         self.stream = torch.cuda.Stream(device=d)
+        # side stream of the fused step's emotion branch (dg_step_rng); MELO_ED_SIDE=0: everything on one stream
+        self.ed_side = torch.cuda.Stream(device=d) if os.environ.get("MELO_ED_SIDE", "1") == "1" else None
         # (Forked side streams for independent branches of a step were implemented and measured in round 1: every
         # fork/join cost more cross-queue latency than the overlap returned once the kernels filled the chip -- 1.70 ms
         # single-stream vs 1.73-1.82 -- and were removed; independent launches of one kernel share a launch instead.)
@@ -751,9 +754,45 @@ class GanEngine:
         generator update follows the critic update on the same batch)."""
         self.draw_randoms_both()
         self.dg_forward()
+        if self.ed_side is not None and os.environ.get("MELO_ED_FLOW") == "ingraph":
+            # The frozen emotion discriminator's branch (a third of the step's MFMA work) needs only the generated batch and
+            # is needed only where the generator's backward starts: it is enqueued on a side stream -- a parallel branch
+            # of the captured graph -- beside the critic step and the critic's pass over the generated batch, whose ~50
+            # launches are mostly small dependent kernels that leave the matrix pipes idle.  One fork, one join.  The
+            # main branch is captured FIRST: hipGraphLaunch feeds a graph's branches to their hardware queues in capture
+            # order, and the branch fed second starts 100-300 us after the fork -- that must not be the critical path
+            # (emotion branch captured first: 0.947 ms/step; critic step first: 0.911; one stream: 0.958).  NOT the
+            # default (MELO_ED_FLOW=ingraph): launching the forked graph costs the host 0.87 ms per step against 0.64
+            # for the plain one -- within 5 % of the GPU's step time -- where the split flow of DataParallel.step needs
+            # 0.58 ms for 0.929.
+            cur = torch.cuda.current_stream()
+            self.ed_side.wait_stream(cur)                 # fork
+            self.d_backward(forward=False)
+            self.d_update()
+            self.g_critic_front()
+            with torch.cuda.stream(self.ed_side):
+                self.g_ed_branch()
+            cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
+            self.g_critic_back()
+        else:
+            self.d_backward(forward=False)
+            self.d_update()
+            self.g_backward_a2()
+        self.g_backward_b()
+        self.g_update()
+
+    # ---- the split flow (DataParallel.step on one GPU, the default MELO_ED_FLOW=split): the emotion branch as its own graph ----
+    def dg_forward_rng(self):
+        self.draw_randoms_both()
+        self.dg_forward()
+
+    def d_step_g_critic_front(self):
         self.d_backward(forward=False)
         self.d_update()
-        self.g_backward_a2()
+        self.g_critic_front()
+
+    def g_finish(self):
+        self.g_critic_back()
         self.g_backward_b()
         self.g_update()
 
@@ -831,11 +870,19 @@ class GanEngine:
     def g_critic_chain(self):
         """Critic forward + input gradient on the generated batch (with the UPDATED critic), added to the emotion
         branch's gradient, then the generator's data-gradient chain down to decoder.pre.2."""
+        self.g_critic_front()
+        self.g_critic_back()
+
+    def g_critic_front(self):
+        """The part of g_critic_chain that does not need the emotion branch's result."""
         B = self.B
-        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         self._d_fwd(self.notes, B, self.emb, head=False)
         self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True)
         ops.neg_mean(self.s[:B], self.adv)
+
+    def g_critic_back(self):
+        B = self.B
+        PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         self._conv5s2("conv_dgrad", self.dZ1[:B], self.D, "conv.0.weight", self.dnotes, accumulate=self.ed_mode == "notes")
         # ---- generator backward: the data-gradient chain down to decoder.pre.2, then pre.2's weight gradient -- 89 % of
         # the generator's gradient bytes, all-reduced while g_backward_b runs.  The deconvolutions' weight gradients
@@ -937,14 +984,15 @@ class GanEngine:
         # An update graph exists in several forms (Adam state advanced by the preceding draw -- with or without the
         # Philox counter to advance -- or by itself); a replayed graph does not run the Python that tracks which one
         # applies, so it is tracked here by sub-step name.
-        fp_upd = {"d_update": self.D, "g_update": self.GE, "d_update_g_critic_chain": self.D}.get(name)
+        fp_upd = {"d_update": self.D, "g_update": self.GE, "d_update_g_critic_chain": self.D,
+                  "d_step_g_critic_front": self.D, "g_finish": self.GE}.get(name)
         key = name + (f"#{fp_upd.ticked}" if fp_upd is not None and fp_upd.ticked else "")
         try:
             return self._run_graph(key, fn)
         finally:
             if name.endswith("_step_rng"):                      # draw and update(s) both inside: nothing left pending
                 self.D.ticked = self.GE.ticked = False
-            elif name == "dg_forward_d_backward_rng":           # the fused draw: both updates are still to come
+            elif name in ("dg_forward_d_backward_rng", "dg_forward_rng"):   # the fused draw: both updates are still to come
                 self.D.ticked, self.GE.ticked = True, "nobump"
             elif name.endswith("_rng"):
                 (self.D if name.startswith("d_") else self.GE).ticked = True

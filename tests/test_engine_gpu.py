@@ -341,3 +341,33 @@ def test_fused_step_matches_the_two_separate_steps(engine_mod):
     assert torch.equal(e3.D.data, e4.D.data) and torch.equal(e3.GE.data, e4.GE.data) and torch.equal(e3.notes, e4.notes)
     assert e3.num_batches_tracked == e4.num_batches_tracked == 8 and int(e4.rng_step.item()) == 4
     assert float(e4.D.state[0].item()) == 4.0 and float(e4.GE.state[0].item()) == 4.0
+
+
+def test_split_flow_equals_the_single_graph_flow(engine_mod):
+    """DataParallel.step on one GPU: back-to-back generator steps run the emotion branch as its own graph on a side stream
+    (four graphs per batch); parameters, optimiser state and losses must equal the one-graph flow bit for bit, also when
+    critic-only batches (which fall back to the one-graph flow) are mixed in."""
+    from melo_gan_amd.gan.dp import DataParallel
+    g = load("gan_c128_t64_b4")
+    res = []
+    for flow in ("none", "split"):
+        os.environ["MELO_ED_FLOW"] = flow
+        try:
+            S, eng, cfg, batch = make(engine_mod, g, use_graph=True)
+            dp = DataParallel(eng, 1, None)
+            eng.seed(5)
+            with torch.cuda.stream(eng.stream):
+                for k, g_step in enumerate((True, True, True, False, True, True, False, False, True, True, True)):
+                    eng.set_batch(*[t.cuda() for t in batch])
+                    dp.step(True, g_step=g_step)
+            torch.cuda.synchronize()
+            res.append((eng.D.data.clone(), eng.GE.data.clone(), eng.GE.m.clone(), float(eng.loss_d_out[0]), float(eng.adv),
+                        float(eng.emo), {k: v.clone() for k, v in eng.Gbuf.items()}, set(eng._graphs)))
+        finally:
+            os.environ.pop("MELO_ED_FLOW", None)
+    a, b = res
+    assert any(k.startswith("g_finish") for k in b[7]) and not any(k.startswith("g_finish") for k in a[7])   # the split flow ran
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3:6] == b[3:6]
+    for k in a[6]:
+        assert torch.equal(a[6][k], b[6][k]), k
