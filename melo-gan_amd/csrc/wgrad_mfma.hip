@@ -503,19 +503,6 @@ __device__ __forceinline__ void wgrad_bias_body(const WgradP& p, const int cb, c
     }
 }
 
-template <int S, int K>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradP p) {
-    const int id = (int)blockIdx.x, gxy = p.gx * p.gy, ntile = gxy * p.gz;
-    if (id < ntile) {
-        const int bz = id / gxy, r = id - bz * gxy;
-        if (wgrad16_applies<S, K>(p)) wgrad16_body<S, K>(p, r % p.gx, r / p.gx, bz);
-        else wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
-    } else {                     // the bias workgroups come last: they fill the slots the first finished tiles leave
-        const int ncb = ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5, k = id - ntile;
-        wgrad_bias_body(p, k % ncb, k / ncb);
-    }
-}
-
 // Several independent weight gradients of one (stride, K) in ONE launch: the small layers' gradients are each a
 // handful of workgroups at the launch floor (~4.7 us per launch and dependent boundary), together they fill the chip
 // once.  Workgroups are numbered job by job; first[j] is job j's first workgroup.
@@ -546,23 +533,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgradJobs J) 
 
 // out[i] = sum_z part[z][i]; 64 elements x 4 slice-groups per block (fixed summation order => reproducible).
 // Elements [0, wn) go to `out` (weight gradient), elements [wn, n) to `bias_out`.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           float* __restrict__ bias_out, long n, long wn, int nsplit) {
-    __shared__ float sh[4][64];
-    const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + ex;
-    float s = 0.f;
-    if (i < n)
-        for (int z = g; z < nsplit; z += 4) s += part[(long)z * n + i];
-    sh[g][ex] = s;
-    __syncthreads();
-    if (g == 0 && i < n) {
-        const float v = (sh[0][ex] + sh[1][ex]) + (sh[2][ex] + sh[3][ex]);
-        if (i < wn) out[i] = v;
-        else bias_out[i - wn] = v;
-    }
-}
-
 struct ReduceJobs {
     const float* part[MG_MAX_WGRAD_JOBS];
     float* out[MG_MAX_WGRAD_JOBS];
@@ -712,31 +682,19 @@ int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, cons
 }
 }  // namespace
 
+extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int stride, void* work, size_t work_bytes,
+                              mg_stream_t stream);
+
+// One weight gradient = a multi-job launch of one job (same kernel, same launch-level plan).
 extern "C" int mg_wgrad(const float* s0, const float* l0, int nb0, const float* s1, const float* l1, int nb1,
                         float* out, float* bias_out, int bias_from, int Ts, int Tl, int A, int Bc, int K, int stride,
                         void* work, size_t work_bytes, mg_stream_t stream) {
-    WgradP p;
-    Plan pl;
-    size_t lds;
-    dim3 grid;
-    const int rc = build_wgrad(s0, l0, nb0, s1, l1, nb1, out, bias_out, bias_from, Ts, Tl, A, Bc, K, stride, work,
-                               work_bytes, p, pl, lds, grid);
-    if (rc != MG_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-#define MG_WG(S_, K_) hipLaunchKernelGGL((wgrad_kernel<S_, K_>), grid, dim3(256), lds, st, p)
-    if (stride == 1) {
-        if (K == 1) MG_WG(1, 1); else if (K == 3) MG_WG(1, 3); else MG_WG(1, 5);
-    } else {
-        MG_WG(2, 5);
-    }
-#undef MG_WG
-    MG_CHECK_LAUNCH("wgrad_kernel");
-    if (pl.nsplit > 1) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)mg_cdiv(p.slab, 64)), dim3(256), 0, st,
-                           (const float*)work, out, bias_out, p.slab, p.wslab, pl.nsplit);
-        MG_CHECK_LAUNCH("reduce_slabs_kernel");
-    }
-    return MG_OK;
+    mg_wgrad_job j{};
+    j.s0 = s0; j.l0 = l0; j.nb0 = nb0;
+    j.s1 = s1; j.l1 = l1; j.nb1 = nb1;
+    j.out = out; j.bias_out = bias_out; j.bias_from = bias_from;
+    j.Ts = Ts; j.Tl = Tl; j.A = A; j.Bc = Bc;
+    return mg_wgrad_multi(&j, 1, K, stride, work, work_bytes, stream);
 }
 
 extern "C" int mg_wgrad_multi(const mg_wgrad_job* jobs, int n_jobs, int K, int stride, void* work, size_t work_bytes,

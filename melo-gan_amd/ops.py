@@ -374,7 +374,7 @@ def wgrad(small: Tensor, large: Tensor, out: Tensor, K: int, stride: int,
         work = workspace(need, small.device, "wgrad")
     if work.numel() * work.element_size() < need:
         raise ValueError("wgrad: workspace too small")
-    with _observe(lambda: f"wgrad_kernel<{stride},{K}>", 2.0 * (nb0 + nb1) * Ts * A * Bc * K):
+    with _observe(lambda: f"wgrad_multi_kernel<{stride},{K}>", 2.0 * (nb0 + nb1) * Ts * A * Bc * K):
         rc = lib.mg_wgrad(_p(small), _p(large), nb0, _p(small2), _p(large2), nb1, _p(out), _p(bias_out), bias_from,
                           Ts, Tl, A, Bc, K, stride, _p(work), work.numel() * work.element_size(), _stream())
     L.check(rc, "mg_wgrad")
