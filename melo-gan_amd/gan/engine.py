@@ -796,6 +796,14 @@ class GanEngine:
         self.g_backward_b()
         self.g_update()
 
+    # the same pieces for the data-parallel step order (collectives in between: DataParallel._step)
+    def d_backward_nofwd(self):
+        self.d_backward(forward=False)
+
+    def d_update_g_critic_front(self):
+        self.d_update()
+        self.g_critic_front()
+
     def dg_forward_d_backward_rng(self):
         """Data parallelism: everything of the fused step in front of the critic's gradient all-reduce."""
         self.draw_randoms_both()
@@ -985,7 +993,7 @@ class GanEngine:
         # Philox counter to advance -- or by itself); a replayed graph does not run the Python that tracks which one
         # applies, so it is tracked here by sub-step name.
         fp_upd = {"d_update": self.D, "g_update": self.GE, "d_update_g_critic_chain": self.D,
-                  "d_step_g_critic_front": self.D, "g_finish": self.GE}.get(name)
+                  "d_step_g_critic_front": self.D, "g_finish": self.GE, "d_update_g_critic_front": self.D}.get(name)
         key = name + (f"#{fp_upd.ticked}" if fp_upd is not None and fp_upd.ticked else "")
         try:
             return self._run_graph(key, fn)
