@@ -413,7 +413,11 @@ def main():
             hook = RecordHook(DOMINANT + CONV16)
             ops.set_launch_hook(hook)
             eng.set_batch(*pool[0])
-            dp.step(False)                     # the production launch sequence, eagerly (the hook sees every launch)
+            # the production launch sequence of one step, eagerly (the hook sees every launch) -- through a LOCAL wrapper:
+            # only rank 0 runs this leg, so it must not issue collectives (it did in an earlier version of this file and
+            # would have left rank 0 waiting for the others in every N > 1 run)
+            DataParallel(eng, 1, None).step(False)
+            eng.world_size = world
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
 
@@ -446,7 +450,7 @@ def main():
                 return ops._NullCtx()
             ops.set_launch_hook(count)
             eng.set_batch(*pool[0])
-            dp.step(False)
+            DataParallel(eng, 1, None).step(False)
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
             with open(args.launch_flops, "w") as f:

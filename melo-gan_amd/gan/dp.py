@@ -19,11 +19,11 @@ A batch's step is a fixed sequence of hipGraphs with the collectives between the
     C3  all-reduce(everything else of the generator / encoder gradient, 2 MB)
     G6  g_update
 
-Since round 2 the emotion branch (G2) is launched on the engine's SIDE stream right after the generator pass -- G1 is
-split into G1a (draw + generator pass) and G1b (critic step's backward), G3 into G3a (critic Adam + critic pass over the
-generated batch) and G3b (from the first use of the emotion branch's gradient on) -- and runs beside G1b, C1 and G3a; the
-main stream joins it in front of G3b (MELO_DP_SIDE=0: the order above on one stream).  Measured on one MI355X with a 1-rank
-RCCL group: gather 1.023 -> 0.984 ms/step, allreduce 0.995 -> 0.957, overlap 1.105 -> 1.049; results bit-identical.
+Optional (MELO_DP_SIDE=1, off by default -- see __init__): the emotion branch (G2) launched on the engine's SIDE stream right
+after the generator pass -- G1 split into G1a (draw + generator pass) and G1b (critic step's backward), G3 into G3a (critic
+Adam + critic pass over the generated batch) and G3b (from the first use of the emotion branch's gradient on) -- beside G1b,
+C1 and G3a; the main stream joins it in front of G3b.  Measured on one MI355X with a 1-rank RCCL group: gather 1.023 -> 0.984
+ms/step, allreduce 0.995 -> 0.957, overlap 1.105 -> 1.049; results bit-identical.
 
 Step orders (MELO_DP_MODE; default "auto" = "overlap" from 8 ranks up, "gather" below):
   gather     every collective synchronous, on the engine's stream, in program order.
@@ -80,8 +80,11 @@ class DataParallel:
         self._pending = []
         self._prepared = False
         self._prev_g = False                                        # was the previous batch a generator step (split flow)
-        # N > 1: the emotion branch on the side stream as well (MELO_DP_SIDE=0: the round-1 order, everything on one stream)
-        self._dp_side = os.environ.get("MELO_DP_SIDE", "1") == "1" and getattr(engine, "ed_dtype", "fp32") == "fp32" \
+        # N > 1: MELO_DP_SIDE=1 puts the emotion branch on the side stream as well.  Off by default: it could only be measured
+        # on a 1-rank RCCL group (-40..-55 us per step in every mode), not with real inter-GPU collectives, and two
+        # processes SHARING one GPU over gloo (the rehearsal setup) fall to 440 ms per step with it (process time slicing
+        # between two queues each) -- the proven one-stream order stays the default for runs nobody could rehearse.
+        self._dp_side = os.environ.get("MELO_DP_SIDE", "0") == "1" and getattr(engine, "ed_dtype", "fp32") == "fp32" \
             and hasattr(engine, "d_update_g_critic_front")
         # split | ingraph | none.  Default: the split flow for the fp32 engine; the bf16-stored emotion branch is a third as
         # long and the three extra graph launches cost more than hiding it returns (0.831 -> 0.872 ms)
