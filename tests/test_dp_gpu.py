@@ -240,3 +240,23 @@ def test_two_engines_as_two_ranks_full_step(mode, monkeypatch):
             upd = fp.p[k].cpu() - P0[k]
             want = -lr * ref / (ref.abs() + 1e-8)
             assert float((upd - want)[mask].abs().max()) <= 2e-2 * lr, (mode, k)
+
+
+def test_bench_runs_to_completion_on_two_ranks():
+    """bench.py's N > 1 path end to end (two ranks sharing this GPU over gloo -- the control path, not the speed): every
+    leg that only rank 0 runs must be free of collectives.  Round 2 had the roofline leg step through the data-parallel
+    wrapper on rank 0 alone, which left rank 0 waiting in an all-reduce the other rank never joined."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MELO_SHARE_GPU="1", MELO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--profile-steps", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["roofline"] is not None
