@@ -191,7 +191,8 @@ class DataParallel:
     # ---- the step --------------------------------------------------------------------------------------------
     def step(self, use_graph: bool = True, g_step: bool = True):
         """One training step (1 critic update, optionally 1 generator update) on the batch already set with
-        engine.set_batch().  world == 1: one graph per batch.  world > 1: the step order of MELO_DP_MODE (module
+        engine.set_batch().  world == 1: one graph per batch, or the split flow below when generator steps follow each
+        other.  world > 1: the step order of MELO_DP_MODE (module
         docstring)."""
         e = self.engine
         if not self.active:
