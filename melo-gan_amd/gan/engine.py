@@ -754,30 +754,34 @@ class GanEngine:
         generator update follows the critic update on the same batch)."""
         self.draw_randoms_both()
         self.dg_forward()
-        if self.ed_side is not None and os.environ.get("MELO_ED_FLOW") == "ingraph":
-            # The frozen emotion discriminator's branch (a third of the step's MFMA work) needs only the generated batch and
-            # is needed only where the generator's backward starts: it is enqueued on a side stream -- a parallel branch
-            # of the captured graph -- beside the critic step and the critic's pass over the generated batch, whose ~50
-            # launches are mostly small dependent kernels that leave the matrix pipes idle.  One fork, one join.  The
-            # main branch is captured FIRST: hipGraphLaunch feeds a graph's branches to their hardware queues in capture
-            # order, and the branch fed second starts 100-300 us after the fork -- that must not be the critical path
-            # (emotion branch captured first: 0.947 ms/step; critic step first: 0.911; one stream: 0.958).  NOT the
-            # default (MELO_ED_FLOW=ingraph): launching the forked graph costs the host 0.87 ms per step against 0.64
-            # for the plain one -- within 5 % of the GPU's step time -- where the split flow of DataParallel.step needs
-            # 0.58 ms for 0.929.
-            cur = torch.cuda.current_stream()
-            self.ed_side.wait_stream(cur)                 # fork
-            self.d_backward(forward=False)
-            self.d_update()
-            self.g_critic_front()
-            with torch.cuda.stream(self.ed_side):
-                self.g_ed_branch()
-            cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
-            self.g_critic_back()
-        else:
-            self.d_backward(forward=False)
-            self.d_update()
-            self.g_backward_a2()
+        self.d_backward(forward=False)
+        self.d_update()
+        self.g_backward_a2()
+        self.g_backward_b()
+        self.g_update()
+
+    def dg_fork_step_rng(self):
+        """dg_step_rng with the frozen emotion discriminator's branch as a PARALLEL BRANCH of the same graph, on the side
+        stream (MELO_ED_FLOW=ingraph; the default of the bf16-stored branch, which is too short for the split flow).  The
+        branch needs only the generated batch and is needed only where the generator's backward starts; the main branch
+        is captured FIRST: hipGraphLaunch feeds a graph's branches to their hardware queues in capture order and the
+        branch fed second starts 100-300 us after the fork -- that must not be the critical path (emotion branch
+        captured first: 0.947 ms/step; critic step first: 0.911; one stream: 0.958).  Launching the forked graph costs the
+        host 0.87 ms per step against 0.64 for the plain one -- within 5 % of the fp32 step's GPU time, which is why the fp32
+        engine takes the split flow (0.58 ms of host time for 0.926) instead."""
+        if self.ed_side is None:
+            return self.dg_step_rng()
+        self.draw_randoms_both()
+        self.dg_forward()
+        cur = torch.cuda.current_stream()
+        self.ed_side.wait_stream(cur)                 # fork
+        self.d_backward(forward=False)
+        self.d_update()
+        self.g_critic_front()
+        with torch.cuda.stream(self.ed_side):
+            self.g_ed_branch()
+        cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
+        self.g_critic_back()
         self.g_backward_b()
         self.g_update()
 

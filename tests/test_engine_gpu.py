@@ -345,12 +345,13 @@ def test_fused_step_matches_the_two_separate_steps(engine_mod):
 
 def test_split_flow_equals_the_single_graph_flow(engine_mod):
     """DataParallel.step on one GPU: back-to-back generator steps run the emotion branch as its own graph on a side stream
-    (four graphs per batch); parameters, optimiser state and losses must equal the one-graph flow bit for bit, also when
-    critic-only batches (which fall back to the one-graph flow) are mixed in."""
+    (four graphs per batch: "split") or as a parallel branch of the one graph ("ingraph"); parameters, optimiser state and
+    losses must equal the one-graph flow bit for bit, also when critic-only batches (which fall back to the one-graph
+    flow) are mixed in."""
     from melo_gan_amd.gan.dp import DataParallel
     g = load("gan_c128_t64_b4")
     res = []
-    for flow in ("none", "split"):
+    for flow in ("none", "split", "ingraph"):
         os.environ["MELO_ED_FLOW"] = flow
         try:
             S, eng, cfg, batch = make(engine_mod, g, use_graph=True)
@@ -365,9 +366,11 @@ def test_split_flow_equals_the_single_graph_flow(engine_mod):
                         float(eng.emo), {k: v.clone() for k, v in eng.Gbuf.items()}, set(eng._graphs)))
         finally:
             os.environ.pop("MELO_ED_FLOW", None)
-    a, b = res
+    a, b, c = res
     assert any(k.startswith("g_finish") for k in b[7]) and not any(k.startswith("g_finish") for k in a[7])   # the split flow ran
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert a[3:6] == b[3:6]
-    for k in a[6]:
-        assert torch.equal(a[6][k], b[6][k]), k
+    assert "dg_fork_step_rng" in c[7]                                                                        # the forked graph ran
+    for o in (b, c):
+        assert torch.equal(a[0], o[0]) and torch.equal(a[1], o[1]) and torch.equal(a[2], o[2])
+        assert a[3:6] == o[3:6]
+        for k in a[6]:
+            assert torch.equal(a[6][k], o[6][k]), k
