@@ -117,6 +117,12 @@ int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin
 int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows, int* tile_rows);
 int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                     long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream);
+/* The same launch also writing the temporal mean of what it stores -- AdaptiveAvgPool1d(1) behind the critic's last
+ * convolution (src/gan/models.py:148): pool[b][n] = pool_scale * sum_t y[b][t][n].  Gather form only; mg_conv16_poolable says
+ * whether a shape qualifies (every sample's time axis is one wave's rows of a tile: Tout = 32, or 16 with 32-row tiles). */
+int mg_conv16_poolable(int B, int Tin, int Cin, int N);
+int mg_conv16_pool(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, long xbs, long ybs,
+                   const mg_epilogue* epi, float* pool, float pool_scale, mg_stream_t stream);
 int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups, const float* z, float* a, long R, int C,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                           float eps, float* save_mean, float* save_invstd, int act, mg_stream_t stream);

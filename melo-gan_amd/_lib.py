@@ -56,6 +56,8 @@ SIGNATURES = {
     "mg_conv16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
     "mg_conv16_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "mg_conv16_stats": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, vp]),
+    "mg_conv16_poolable": (i32, [i32, i32, i32, i32]),
+    "mg_conv16_pool": (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, f32, vp]),
     "mg_bn_train_fwd_parts": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp]),
     "mg_linear_workspace_bytes": (sz, [i32, i32, i32]),
     "mg_linear": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp, sz, vp]),

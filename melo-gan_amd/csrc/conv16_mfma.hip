@@ -40,6 +40,11 @@ struct Conv16P {
     // optional per-column statistics of the stored values v (the BatchNorm that follows needs no reduction pass): every
     // wave writes, for its 16 columns, part[(2*mtile + wm)][0][n] = sum v and [1][n] = sum v*v over its valid rows
     float* part;
+    // optional temporal mean of the stored values (AdaptiveAvgPool1d(1) behind the critic's last convolution,
+    // src/gan/models.py:148): pool[b][n] = pool_scale * sum_t v[b][t][n], written by the wave whose rows are sample b's whole
+    // time axis (host checked: one 16*RT-row wave tile per sample) -- the pooling launch and its dependent boundary disappear
+    float* pool;
+    float pool_scale;
 };
 
 constexpr int K5 = 5;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] *= gscale;
-            if (p.part) {
+            if (p.part || p.pool) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (ok[r]) {
@@ -319,14 +324,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
             for (int r = 0; r < 4; ++r)
                 if (ok[r]) p.y[yi[r]] = a[r];
         }
-    if (p.part) {        // the four lanes of a column (row groups kq = 0..3) -> one partial per wave and column
+    if (p.part || p.pool) {        // the four lanes of a column (row groups kq = 0..3) -> one partial per wave and column
         st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
         st2 += __shfl_xor(st2, 16, 64); st2 += __shfl_xor(st2, 32, 64);
-        if (kq == 0) {
+        if (kq == 0 && p.part) {
             float* dst = p.part + (long)(2 * blockIdx.x + wm) * 2 * p.N + n;
             dst[0] = st1;
             dst[p.N] = st2;
         }
+        if (kq == 0 && p.pool && 2 * (int)blockIdx.x + wm < p.B) p.pool[(long)(2 * blockIdx.x + wm) * p.N + n] = st1 * p.pool_scale;
     }
 }
 
@@ -431,6 +437,24 @@ extern "C" int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_
 
 extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                                long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream);
+static int conv16_launch(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+                         long xbs, long ybs, const mg_epilogue* epi, float* part, float* pool, float pool_scale, mg_stream_t stream);
+
+// 1 if a launch of this shape can also write the temporal mean of its output: gather form, every sample's time axis is
+// exactly one wave's rows of a tile (Tout = 32 with 64-row tiles, 16 with 32-row tiles)
+extern "C" int mg_conv16_poolable(int B, int Tin, int Cin, int N) {
+    if (!mg_conv16_supported(B, Tin, Cin, N, 0, 0)) return 0;
+    const int Tm = (Tin + 4 - K5) / 2 + 1;
+    return Tm == 16 * pick_rt((long)B * Tm, N);
+}
+
+extern "C" int mg_conv16_pool(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, long xbs, long ybs,
+                              const mg_epilogue* epi, float* pool, float pool_scale, mg_stream_t stream) {
+    MG_CHECK_ARG(pool != nullptr, "mg_conv16_pool: null pool tensor");
+    MG_CHECK_ARG(mg_conv16_poolable(B, Tin, Cin, N), "mg_conv16_pool: shape B=%d Tin=%d Cin=%d N=%d is not poolable", B, Tin, Cin, N);
+    MG_CHECK_ARG(!(epi && epi->accumulate), "mg_conv16_pool: the mean of an accumulating launch is not defined");
+    return conv16_launch(x, wq, y, B, Tin, Cin, N, 0, 0, xbs, ybs, epi, nullptr, pool, pool_scale, stream);
+}
 
 extern "C" int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                          long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream) {
@@ -439,6 +463,11 @@ extern "C" int mg_conv16(const float* x, const float* wq, float* y, int B, int T
 
 extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                                long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream) {
+    return conv16_launch(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, part, nullptr, 0.f, stream);
+}
+
+static int conv16_launch(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+                         long xbs, long ybs, const mg_epilogue* epi, float* part, float* pool, float pool_scale, mg_stream_t stream) {
     MG_CHECK_ARG(x && wq && y, "mg_conv16: null tensor");
     MG_CHECK_ARG(!(part && epi && epi->accumulate), "mg_conv16: statistics of an accumulating launch are not defined");
     const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
@@ -458,6 +487,8 @@ extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B,
         MG_CHECK_ARG(!(p.e.scale && !p.e.shift), "epilogue: scale without shift");
     }
     p.part = part;
+    p.pool = pool;
+    p.pool_scale = pool_scale;
     hipStream_t s = (hipStream_t)stream;
     const int rt = pick_rt((long)B * Tm, N);
     int rc;

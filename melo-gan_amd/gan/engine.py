@@ -356,12 +356,14 @@ class GanEngine:
             ops.wq_relayout(fp.p[name], t, N, Cc, 5, sn, sc)
         self._ed_folded = False
 
-    def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, stats=None, **epi):
+    def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, stats=None, pool=None, **epi):
         """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
         convT_fwd / convT_dgrad (nn.ConvTranspose1d, weight (Cin,Cout,5)).  conv16 (no split-K, no finish launch) wherever
         it covers the shape (faster on every cfg2 layer, tools/conv16_bench.py); the 64x64-tile kernel otherwise.
         stats = rows per BatchNorm group: ask the launch for per-column partial statistics of what it stores (the
-        BatchNorm that follows then needs no reduction pass).  Returns (part, part_rows) if it did, else None."""
+        BatchNorm that follows then needs no reduction pass).  Returns (part, part_rows) if it did, else None.
+        pool = (B, N) tensor: also write the temporal mean of the output there if the launch can (returns True), else the
+        caller runs the pooling kernel (returns None)."""
         w = fp.p[name]
         transposed = kind in ("conv_dgrad", "convT_fwd")
         direction = "fwd" if kind.endswith("fwd") else "dgrad"
@@ -370,6 +372,9 @@ class GanEngine:
         B, Tin, Cin = x.shape
         odd = transposed and y.shape[1] == 2 * Tin - 1 and kind == "conv_dgrad"
         if wq is not None and ops.conv16_supported(B, Tin, Cin, N, transposed, (2 * Tin - (1 if odd else 0)) if transposed else 0):
+            if pool is not None and kind == "conv_fwd" and ops.conv16_poolable(B, Tin, Cin, N):
+                ops.conv16_pool(x, wq, y, N, pool, 1.0 / y.shape[1], **epi)
+                return True
             if stats is not None:
                 tb, rows = ops.conv16_plan(B, Tin, N, transposed)
                 if stats % tb == 0:                 # no tile straddles two groups
@@ -588,8 +593,10 @@ class GanEngine:
         P = self.D.p
         self._conv5s2("conv_fwd", x, self.D, "conv.0.weight", self.A1[:nb], bias=P["conv.0.bias"], act=ACT_LRELU)
         self._conv5s2("conv_fwd", self.A1[:nb], self.D, "conv.2.weight", self.A2[:nb], bias=P["conv.2.bias"], act=ACT_LRELU)
-        self._conv5s2("conv_fwd", self.A2[:nb], self.D, "conv.4.weight", self.A3[:nb], bias=P["conv.4.bias"], act=ACT_LRELU)
-        ops.meanT_fwd(self.A3[:nb], self.H[:nb])
+        # AdaptiveAvgPool1d(1) rides in conv.4's launch where a sample's time axis is one wave tile (cfg2: 32 positions)
+        if not self._conv5s2("conv_fwd", self.A2[:nb], self.D, "conv.4.weight", self.A3[:nb], pool=self.H[:nb],
+                             bias=P["conv.4.bias"], act=ACT_LRELU):
+            ops.meanT_fwd(self.A3[:nb], self.H[:nb])
         ops.linear_fwd(self.H[:nb], P["fc.1.weight"], self.Fh[:nb], bias=P["fc.1.bias"], act=ACT_LRELU)
         if head:
             ops.dhead_fwd(self.Fh[:nb], emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb])
@@ -703,7 +710,8 @@ class GanEngine:
         # masked linear critic).
         self._conv5s2("conv_fwd", self.TAN0, self.D, "conv.0.weight", self.TAN1, gref=self.A1[:B], gact=ACT_LRELU)
         self._conv5s2("conv_fwd", self.TAN1, self.D, "conv.2.weight", self.TAN2, gref=self.A2[:B], gact=ACT_LRELU)
-        self._conv5s2("conv_fwd", self.TAN2, self.D, "conv.4.weight", self.TZ3, gref=self.A3[:B], gact=ACT_LRELU)
+        tz3_pooled = self._conv5s2("conv_fwd", self.TAN2, self.D, "conv.4.weight", self.TZ3, pool=self.ghb, gref=self.A3[:B],
+                                   gact=ACT_LRELU)
         # the three convolutions' weight gradients go out as ONE launch (+ one slab reduction) once their tangents
         # exist (ops.wgrad_multi): three launches of ~256 workgroups each plus three reductions before
         ops.wgrad_multi([
@@ -713,7 +721,8 @@ class GanEngine:
                              db=G["conv.2.bias"], defer=True),
             ops.conv1d_wgrad(self.A2[B:], self.dZ3[B:], G["conv.4.weight"], 2, self.TAN2, self.dZ3[:B],
                              db=G["conv.4.bias"], defer=True)])
-        ops.meanT_fwd(self.TZ3, self.ghb)
+        if not tz3_pooled:
+            ops.meanT_fwd(self.TZ3, self.ghb)
         ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[:B], gact=ACT_LRELU)
         ops.linear_wgrad(self.H[B:], self.dU[B:], G["fc.1.weight"], self.ghb, self.dU[:B], db=G["fc.1.bias"])
         ops.dhead_wgrad(self.ds_d[B:], self.Fh[B:], self.emb_d, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"],

@@ -220,6 +220,31 @@ def conv16_supported(B: int, Tin: int, Cin: int, N: int, transposed: bool, Tout:
     return bool(L.load().mg_conv16_supported(B, Tin, Cin, N, 1 if transposed else 0, Tout))
 
 
+def conv16_poolable(B: int, Tin: int, Cin: int, N: int) -> bool:
+    return bool(L.load().mg_conv16_poolable(B, Tin, Cin, N))
+
+
+def conv16_pool(x: Tensor, wq: Tensor, y: Tensor, N: int, pool: Tensor, scale: float, **epi) -> Tensor:
+    """conv16 (gather form) that also writes pool[b][n] = scale * sum_t y[b][t][n] (mg_conv16_pool)."""
+    _chk(x, "x")
+    _chk(wq, "wq")
+    _chk(y, "y")
+    B, Tin, Cin = x.shape
+    Tout = (Tin - 1) // 2 + 1
+    if tuple(y.shape) != (B, Tout, N):
+        raise ValueError(f"y: expected {(B, Tout, N)}, got {tuple(y.shape)}")
+    _chk(pool, "pool", (B, N))
+    e = epilogue((B, Tout, N), N, **epi)
+    lib = L.load()
+    def launch():
+        return lib.mg_conv16_pool(_p(x), _p(wq), _p(y), B, Tin, Cin, N, Tin * Cin, Tout * N, C.byref(e), _p(pool), float(scale),
+                                  _stream())
+    with _observe(lambda: "conv16_kernel<false,%d>" % (_conv16_plan(B, Tin, N, False)[2] // 32), 2.0 * B * Tout * N * Cin * 5, launch):
+        rc = launch()
+    L.check(rc, "mg_conv16_pool")
+    return y
+
+
 def conv16_plan(B: int, Tin: int, N: int, transposed: bool):
     """(batch rows one tile spans, partial-statistics rows a launch writes) of mg_conv16's tiling for a shape."""
     return _conv16_plan(B, Tin, N, transposed)[:2]

@@ -128,3 +128,33 @@ def test_batchnorm_from_the_convolutions_partial_statistics(ops, B, L, Cin, Cout
     zg = z.cpu().view(groups, B // groups, 2 * L, Cout)
     ref = torch.stack([F.relu(F.batch_norm(zg[g].reshape(-1, Cout), None, None, gamma, beta, True, 0.1, 1e-5)) for g in range(groups)])
     close(a1, ref.view(B, 2 * L, Cout), 2e-5)
+
+
+@pytest.mark.parametrize("B,Tin,Cin,N", [(192, 64, 128, 256), (64, 64, 128, 256), (3, 64, 32, 64), (5, 63, 64, 96)])
+def test_conv16_pool_is_the_temporal_mean_of_the_output(B, Tin, Cin, N):
+    """mg_conv16_pool: AdaptiveAvgPool1d(1) of the activated output from the convolution's own launch (critic conv.4 ->
+    pooling, src/gan/models.py:141-148) equals the mean over time of what the launch stored, for full and ragged batch
+    tiles, with the bias + LeakyReLU and the tangent-pass epilogues; shapes that do not qualify are refused."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    g = torch.Generator().manual_seed(B + Tin)
+    x = torch.randn(B, Tin, Cin, generator=g).cuda()
+    w = (torch.randn(N, Cin, 5, generator=g) * 0.05).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    wq = torch.empty(N * Cin * 5, device="cuda")
+    ops.wq_relayout(w, wq, N, Cin, 5, Cin * 5, 5)
+    Tout = (Tin - 1) // 2 + 1
+    assert ops.conv16_poolable(B, Tin, Cin, N) == (Tout == 32)
+    y, pool = torch.empty(B, Tout, N, device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+    if Tout != 32:
+        with pytest.raises(RuntimeError):
+            ops.conv16_pool(x, wq, y, N, pool, 1.0 / Tout, bias=b, act=ops.ACT_LRELU)
+        return
+    ops.conv16_pool(x, wq, y, N, pool, 1.0 / Tout, bias=b, act=ops.ACT_LRELU)
+    y2 = torch.empty_like(y)
+    ops.conv16(x, wq, y2, N, False, bias=b, act=ops.ACT_LRELU)
+    assert torch.equal(y, y2)
+    torch.testing.assert_close(pool, y.double().mean(dim=1).float(), rtol=1e-5, atol=1e-6)
+    ref = torch.randn(B, Tout, N, generator=g).cuda()
+    ops.conv16_pool(x, wq, y, N, pool, 1.0 / Tout, gref=ref, gact=ops.ACT_LRELU)
+    torch.testing.assert_close(pool, y.double().mean(dim=1).float(), rtol=1e-5, atol=1e-6)
