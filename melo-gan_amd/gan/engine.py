@@ -194,6 +194,9 @@ class GanEngine:
         self.GE = FlatParams(ge, d, first=["G.decoder.pre.2.weight", "G.decoder.pre.2.bias"])
         self.D = FlatParams(discriminator_spec(C, 256, self.E), d)
         edspec, edbufs, self.ed_chans = emotion_disc_spec(self.ed_cfg)
+        if self.ed_mode == "notes" and self.ed_chans and self.ed_chans[0][0] != C:
+            raise ValueError(f"emotion discriminator config: note_dim={self.ed_chans[0][0]} but the GAN's NOTE_DIM={C} -- the "
+                             "frozen classifier reads the generated notes, both must agree (ed_model.py:24, models.py:67)")
         self.ED = FlatParams(edspec, d, with_opt=False)
         self.EDbuf = {k: (torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d))
                       for k, s in edbufs.items()}
