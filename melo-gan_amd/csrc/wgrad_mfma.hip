@@ -38,6 +38,7 @@ struct WgradP {
     int bias_from;  // 0: none; 1: column sums of S (Conv1d / Linear bias); 2: column sums of L (ConvTranspose1d bias)
     int nseg_bias;  // how many segments contribute to the bias (penalty segment never does)
     int vec_ok;     // all four tensors 16-byte aligned and < 2 GiB (raw-buffer float4 path)
+    int lin;        // K = 1, Ts = 1, aligned: the 32 x 128-tile Linear body (wgrad_lin_body)
     int gx, gy, gz; // output tiles along A and Bc, slices; the launch starts with gz * ceil(C / 32) bias workgroups (bias_from != 0)
 };
 
@@ -448,6 +449,71 @@ __device__ __forceinline__ void wgrad16_body(const WgradP& p, const int bx, cons
     MG_STAMP(3);
 }
 
+// ---- Linear layers (K = 1, one row per batch element): 32 x 128 output tiles -------------------------------------------
+// dW[a][b] = sum_r dy[r][a] * x[r][b] over <= a few hundred rows: almost no reduction, all output.  With the 32 x 32 tiles
+// of the bodies above decoder.pre.2 (8192 x 512, 64 rows) was 4096 workgroups of ONE 64-row chunk each -- prologue and
+// epilogue around 16 MFMAs per wave, 16 us for a 16.8-MB write.  Here a workgroup stages its 32 dy-columns once per
+// 64-row chunk and each of its four waves multiplies them with its own 32 x-columns: 4x fewer workgroups, the S rows
+// fetched once instead of four times, the 32 x 32 accumulator stored straight from registers (a lane's 32-lane row group
+// is 128 contiguous bytes of dW).  Same slices / slabs / bias workgroups as the other bodies.
+constexpr int LIN_BB = 128;
+__device__ __forceinline__ bool wgrad_lin_applies(const WgradP& p) {
+    return p.lin != 0;
+}
+__device__ __forceinline__ void wgrad_lin_body(const WgradP& p, const int bx, const int by, const int bz) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SPL = 36, LPL = 132;                   // LDS pitches: row pairs of a half-wave on disjoint banks
+    float* Ss = smem;                                    // [64][SPL]
+    float* Ls = smem + RT * SPL;                         // [64][LPL]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int a0 = bx * BA, b0 = by * LIN_BB;
+    const int TB = RT;                                   // Ts = 1: a batch group is 64 rows
+    const int g_begin = bz * p.bps, g_end = min(g_begin + p.bps, p.n_bgroups);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int g = g_begin; g < g_end; ++g) {
+        const int seg_id = g < p.nbg0 ? 0 : 1;
+        const int bb0 = (seg_id ? g - p.nbg0 : g) * TB;
+        const int nb = p.nb[seg_id];
+        const float* Sp = p.s[seg_id] + (long)bb0 * p.A;
+        const float* Lp = p.l[seg_id] + (long)bb0 * p.Bc;
+        const int rows = min(TB, nb - bb0);
+        __syncthreads();
+        // S: 64 rows x 8 quads = 512 float4 (2 per thread); L: 64 rows x 32 quads = 2048 float4 (8 per thread); rows past the
+        // segment and columns past the matrix are staged as zeros (row-clamped unconditional loads, selected afterwards)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 3, q = idx & 7;
+            const bool ok = r < rows && a0 + 4 * q < p.A;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Sp + (long)(ok ? r : 0) * p.A + (ok ? a0 + 4 * q : 0));
+            *reinterpret_cast<f32x4*>(Ss + r * SPL + 4 * q) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j, r = idx >> 5, q = idx & 31;
+            const bool ok = r < rows && b0 + 4 * q < p.Bc;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Lp + (long)(ok ? r : 0) * p.Bc + (ok ? b0 + 4 * q : 0));
+            *reinterpret_cast<f32x4*>(Ls + r * LPL + 4 * q) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r2 = 0; r2 < RT / 2; ++r2) {
+            const int r = 2 * r2 + h;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ss[r * SPL + c], Ls[r * LPL + 32 * wave + c], acc, 0, 0, 0);
+        }
+    }
+    float* out = p.part ? p.part + (long)bz * p.slab : p.out;
+    const int b = b0 + 32 * wave + c;
+    if (b < p.Bc) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int a = a0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (a < p.A) out[(long)a * p.Bc + b] = acc[i];
+        }
+    }
+}
+
 // The bias gradient -- column sums of S (Conv1d / Linear: bias_from 1) or of L (ConvTranspose1d: 2) over the segments
 // that carry one -- is the work of EXTRA workgroups of the same launch, one per (slice, 32-column block): a streaming
 // sum of the slice's rows (a few hundred rows x 128 B, ~1-2 us) into the slab's bias entries, which the slab reduction
@@ -523,7 +589,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgradJobs J) 
     const WgradP& p = J.p[j];          // a reference: the by-value copy landed in scratch memory once two bodies used it
     if (tile) {
         const int gxy = p.gx * p.gy, bz = b / gxy, r = b - bz * gxy;
-        if (wgrad16_applies<S, K>(p)) wgrad16_body<S, K>(p, r % p.gx, r / p.gx, bz);
+        if (K == 1 && wgrad_lin_applies(p)) wgrad_lin_body(p, r % p.gx, r / p.gx, bz);
+        else if (wgrad16_applies<S, K>(p)) wgrad16_body<S, K>(p, r % p.gx, r / p.gx, bz);
         else wgrad_body<S, K>(p, r % p.gx, r / p.gx, bz);
     } else {
         const int ncb = ((p.bias_from == 1 ? p.A : p.Bc) + 31) >> 5;
@@ -675,7 +742,15 @@ int build_wgrad(const float* s0, const float* l0, int nb0, const float* s1, cons
         }
     }
     lds = lds_floats * sizeof(float);
-    p.gx = (int)mg_cdiv(A, BA); p.gy = (int)mg_cdiv(Bc, BB); p.gz = pl.nsplit;
+    // (only where the wide tiles still fill the chip: the small Linear layers -- 16-64 tiles of 32 x 128 -- are faster on four
+    //  times as many 32 x 32 tiles: critic fc 5.1 against 7.9 us)
+    p.lin = (K == 1 && stride == 1 && Ts == 1 && Tl == 1 && (A & 3) == 0 && (Bc & 3) == 0 && p.vec_ok &&
+             mg_cdiv(A, BA) * mg_cdiv(Bc, LIN_BB) >= 128) ? 1 : 0;
+    if (p.lin) {
+        const size_t lin_floats = (size_t)RT * (36 + 132);
+        if (lds < lin_floats * sizeof(float)) lds = lin_floats * sizeof(float);
+    }
+    p.gx = (int)mg_cdiv(A, BA); p.gy = (int)mg_cdiv(Bc, p.lin ? LIN_BB : BB); p.gz = pl.nsplit;
     const int nbias = bias_from ? pl.nsplit * (int)mg_cdiv(bias_from == 1 ? A : Bc, 32) : 0;
     grid = dim3((unsigned)(p.gx * p.gy * p.gz + nbias));      // 1-D: the tile workgroups, then the bias workgroups
     return MG_OK;
