@@ -74,11 +74,41 @@ def save_checkpoint(eng: GanEngine, path: str, epoch=None, full=True):
     if not full:
         torch.save({"G": sd["G"], "E_num": sd["E_num"]}, path)
         return
-    opt = lambda fp, lr: {"state": {"step": float(fp.state[0].item()), "exp_avg": fp.m.cpu(), "exp_avg_sq": fp.v.cpu()},  # noqa: E731
-                          "param_groups": [{"lr": lr, "betas": eng.betas, "eps": 1e-8, "weight_decay": 0}],
-                          "layout": {k: list(v) for k, v in fp.offsets.items()}}
+    betas = tuple(eng.betas)
     torch.save({"epoch": epoch, "G": sd["G"], "D": sd["D"], "E_num": sd["E_num"],
-                "opt_G": opt(eng.GE, eng.lr_g), "opt_D": opt(eng.D, eng.lr_d)}, path)
+                "opt_G": adam_state_dict(eng.GE, eng.lr_g, betas), "opt_D": adam_state_dict(eng.D, eng.lr_d, betas)}, path)
+
+
+def adam_state_dict(fp, lr: float, betas, eps: float = 1e-8, weight_decay: float = 0.0) -> dict:
+    """The flat optimiser state as `torch.optim.Adam.state_dict()` of the reference's optimisers (train_gan.py:136-145:
+    opt_G over list(G.parameters()) + list(E_num.parameters()), opt_D over D.parameters()): parameter i of the optimiser is
+    entry i of the flat buffer's spec (module definition order, the generator's tensors before the numeric encoder's), with
+    its own `step`, `exp_avg`, `exp_avg_sq`.  `optimizer.load_state_dict()` of a reference trainer accepts it as is."""
+    step = float(fp.state[0].item())
+    state = {}
+    for i, k in enumerate(fp.spec):
+        off, n = fp.offsets[k]
+        state[i] = {"step": torch.tensor(step, dtype=torch.float32),
+                    "exp_avg": fp.m[off:off + n].view(fp.spec[k]).detach().cpu().clone(),
+                    "exp_avg_sq": fp.v[off:off + n].view(fp.spec[k]).detach().cpu().clone()}
+    group = {"lr": float(lr), "betas": tuple(float(b) for b in betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False,
+             "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+             "params": list(range(len(fp.spec)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_adam_state_dict(fp, sd: dict):
+    """Inverse of adam_state_dict (resume): fills the flat moment buffers, the step counter and the running beta powers
+    the update kernel keeps beside it (state = [step, beta1^step, beta2^step, -])."""
+    for i, k in enumerate(fp.spec):
+        off, n = fp.offsets[k]
+        st = sd["state"][i]
+        fp.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(fp.m.device))
+        fp.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(fp.v.device))
+    if sd["state"]:
+        step = float(sd["state"][0]["step"])
+        b1, b2 = sd["param_groups"][0]["betas"]
+        fp.state[0], fp.state[1], fp.state[2] = step, float(b1) ** step, float(b2) ** step
 
 
 def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: bool = True):

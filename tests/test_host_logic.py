@@ -32,3 +32,33 @@ def test_plateau_matches_torch_reduce_lr_on_plateau():
         sch.step(float(m))
         lr = mine.step(float(m), lr)
         assert lr == opt.param_groups[0]["lr"]
+
+
+def test_optimizer_checkpoint_is_a_torch_adam_state_dict():
+    """opt_G / opt_D of gan_epochNNNN.pth (reference train_gan.py:267-276) are `torch.optim.Adam.state_dict()`s of the
+    reference's optimisers: a torch Adam over parameters of the same shapes, in the same order, loads them as they are --
+    and the flat buffers take them back (resume)."""
+    import torch
+    from collections import OrderedDict
+    from melo_gan_amd.gan.engine import FlatParams
+    from melo_gan_amd.gan.train_gan import adam_state_dict, load_adam_state_dict
+    spec = OrderedDict([("a.weight", (3, 4)), ("a.bias", (3,)), ("b.weight", (2, 3, 5))])
+    fp = FlatParams(spec, "cpu", first="b.weight")           # flat order differs from the spec's order on purpose
+    g = torch.Generator().manual_seed(0)
+    fp.m.copy_(torch.randn(fp.m.shape, generator=g))
+    fp.v.copy_(torch.rand(fp.v.shape, generator=g))
+    fp.state[0] = 7.0
+    sd = adam_state_dict(fp, 2e-4, (0.5, 0.9))
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in spec.values()]
+    opt = torch.optim.Adam(params, lr=1.0, betas=(0.1, 0.2))
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["lr"] == 2e-4 and tuple(opt.param_groups[0]["betas"]) == (0.5, 0.9)
+    for i, k in enumerate(spec):
+        off, n = fp.offsets[k]
+        assert torch.equal(opt.state[params[i]]["exp_avg"], fp.m[off:off + n].view(spec[k]))
+        assert torch.equal(opt.state[params[i]]["exp_avg_sq"], fp.v[off:off + n].view(spec[k]))
+        assert float(opt.state[params[i]]["step"]) == 7.0
+    fp2 = FlatParams(spec, "cpu", first="b.weight")
+    load_adam_state_dict(fp2, opt.state_dict())
+    assert torch.equal(fp2.m[:fp.n], fp.m[:fp.n]) and torch.equal(fp2.v[:fp.n], fp.v[:fp.n])
+    assert float(fp2.state[0]) == 7.0 and abs(float(fp2.state[1]) - 0.5 ** 7) < 1e-15 and abs(float(fp2.state[2]) - 0.9 ** 7) < 1e-15
