@@ -59,13 +59,28 @@ def load_ed_checkpoint(eng: GanEngine, path: str):
     ckpt = torch.load(path, map_location="cpu")
     sd = ckpt["model"] if "model" in ckpt else ckpt
     for k in eng.ED.spec:
-        if k in sd and tuple(sd[k].shape) == tuple(eng.ED.spec[k]):
-            eng.ED.p[k].copy_(sd[k].float())
+        w = spectral_norm_weight(sd, k)
+        if w is not None and tuple(w.shape) == tuple(eng.ED.spec[k]):
+            eng.ED.p[k].copy_(w.float())
     for k in eng.EDbuf:
         if k in sd:
             eng.EDbuf[k].copy_(sd[k].float())
     eng._ed_folded = False
     return True
+
+
+def spectral_norm_weight(sd: dict, key: str):
+    """sd[key], or -- for a layer the reference wrapped in nn.utils.spectral_norm (`use_spectral_norm`, ed_model.py:29-32,
+    79-82: state_dict keys `<key>_orig`, `<key>_u`, `<key>_v`) -- the weight that wrapper uses in eval mode:
+    weight_orig / sigma with sigma = u^T W v over W = weight_orig flattened to (out, -1), no power iteration.  The GAN step
+    only ever runs the emotion discriminator frozen and in eval mode, so folding sigma in at load time is exact."""
+    if key in sd:
+        return sd[key]
+    if key + "_orig" in sd and key + "_u" in sd and key + "_v" in sd:
+        w = sd[key + "_orig"].double()
+        sigma = torch.dot(sd[key + "_u"].double(), w.flatten(1).mv(sd[key + "_v"].double()))
+        return (w / sigma).float()
+    return None
 
 
 def save_checkpoint(eng: GanEngine, path: str, epoch=None, full=True):

@@ -62,3 +62,23 @@ def test_optimizer_checkpoint_is_a_torch_adam_state_dict():
     load_adam_state_dict(fp2, opt.state_dict())
     assert torch.equal(fp2.m[:fp.n], fp.m[:fp.n]) and torch.equal(fp2.v[:fp.n], fp.v[:fp.n])
     assert float(fp2.state[0]) == 7.0 and abs(float(fp2.state[1]) - 0.5 ** 7) < 1e-15 and abs(float(fp2.state[2]) - 0.9 ** 7) < 1e-15
+
+
+def test_spectral_norm_checkpoint_weights_fold_at_load():
+    """A frozen emotion discriminator trained with use_spectral_norm (ed_model.py:29-32): the weight its eval-mode forward
+    uses is weight_orig / (u^T W v); train_gan.spectral_norm_weight reproduces what torch's wrapper computes."""
+    import torch
+    from melo_gan_amd.gan.train_gan import spectral_norm_weight
+    torch.manual_seed(0)
+    conv = torch.nn.utils.spectral_norm(torch.nn.Conv1d(4, 8, 5, padding=2))
+    lin = torch.nn.utils.spectral_norm(torch.nn.Linear(6, 3))
+    for m in (conv, lin):                     # a few training-mode forwards move u / v, as training would
+        m.train()
+        for _ in range(3):
+            m(torch.randn(2, 4, 16) if m is conv else torch.randn(2, 6))
+        m.eval()
+        m(torch.randn(2, 4, 16) if m is conv else torch.randn(2, 6))        # eval forward: sets .weight from the stored u, v
+        sd = {"x." + k: v for k, v in m.state_dict().items()}
+        got = spectral_norm_weight(sd, "x.weight")
+        torch.testing.assert_close(got, m.weight.detach(), rtol=1e-6, atol=1e-7)
+    assert spectral_norm_weight({"x.weight": torch.ones(2)}, "x.weight").sum() == 2 and spectral_norm_weight({}, "x.weight") is None
