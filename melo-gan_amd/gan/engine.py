@@ -357,7 +357,9 @@ class GanEngine:
         refreshes the derived copies -- the WQ-layout convolution weights and the folded emotion discriminator."""
         for fp, name, t, N, Cc, sn, sc in self._wq_src:
             ops.wq_relayout(fp.p[name], t, N, Cc, 5, sn, sc)
-        self._ed_folded = False
+        # folded eagerly, never from inside a sub-step: a replayed hipGraph does not run the Python that would notice a
+        # stale fold (and a fold launched during capture would be baked into every replay)
+        self.fold_ed()
 
     def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, stats=None, pool=None, **epi):
         """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
@@ -618,8 +620,14 @@ class GanEngine:
         self._conv5s2("conv_dgrad", self.dZ3[:nb], self.D, "conv.4.weight", self.dZ2[:nb], gref=self.A2[:nb], gact=ACT_LRELU)
         self._conv5s2("conv_dgrad", self.dZ2[:nb], self.D, "conv.2.weight", self.dZ1[:nb], gref=self.A1[:nb], gact=ACT_LRELU)
 
+    def _require_fold(self):
+        if not self._ed_folded:
+            raise RuntimeError("GanEngine: the frozen emotion discriminator's parameters were written without "
+                               "params_changed() -- its folded scale/shift and re-laid weights are stale")
+
     def fold_ed(self):
-        """Eval-mode BatchNorm of the frozen ED folded with its conv bias into scale/shift (once)."""
+        """Eval-mode BatchNorm of the frozen ED folded with its conv bias into scale/shift; called by params_changed()
+        (load_state, init_weights, load_ed_checkpoint, broadcast), outside any graph."""
         for i in range(len(self.ed_chans)):
             pre = f"encoder.conv.{i}.net"
             ops.bn_fold(self.ED.p[pre + ".1.weight"], self.ED.p[pre + ".1.bias"], self.EDbuf[pre + ".1.running_mean"],
@@ -756,8 +764,7 @@ class GanEngine:
         """E_num + generator forward of the critic step AND of the generator step as one pass over 2B rows: both use the
         same weights (train_gan.py:186-189 and :216-219 -- the generator is not updated in between), each half has its own
         noise, dropout masks and BatchNorm batch statistics, and the running statistics move twice, critic-step half first."""
-        if not self._ed_folded:
-            self.fold_ed()
+        self._require_fold()
         self._e_fwd(True, "both")
         self._g_fwd(self.X0[2 * self.B:], True, "both")
 
@@ -772,7 +779,7 @@ class GanEngine:
         self.g_backward_b()
         self.g_update()
 
-    def dg_fork_step_rng(self):
+    def dg_fork_step_rng(self, draw: bool = True):
         """dg_step_rng with the frozen emotion discriminator's branch as a PARALLEL BRANCH of the same graph, on the side
         stream (MELO_ED_FLOW=ingraph; the default of the bf16-stored branch, which is too short for the split flow).  The
         branch needs only the generated batch and is needed only where the generator's backward starts; the main branch
@@ -783,7 +790,8 @@ class GanEngine:
         engine takes the split flow (0.58 ms of host time for 0.926) instead."""
         if self.ed_side is None:
             return self.dg_step_rng()
-        self.draw_randoms_both()
+        if draw:                                      # draw=False: the randoms were injected (parity tests)
+            self.draw_randoms_both()
         self.dg_forward()
         cur = torch.cuda.current_stream()
         self.ed_side.wait_stream(cur)                 # fork
@@ -861,8 +869,7 @@ class GanEngine:
     def g_forward(self):
         """E_num + generator forward of the G-step: independent of the critic, so under data parallelism it runs while
         the critic's gradient all-reduce is in flight (DataParallel.step)."""
-        if not self._ed_folded:
-            self.fold_ed()
+        self._require_fold()
         self._e_fwd(True, "g")
         self._g_fwd(self.notes, True, "g")
 
@@ -885,8 +892,7 @@ class GanEngine:
         """The frozen emotion discriminator's forward, cross-entropy and input gradient on the generated batch: the only
         part of the generator step that does not touch the critic -- under data parallelism it runs while the critic's
         gradient all-reduce is in flight (DataParallel.step)."""
-        if not self._ed_folded:
-            self.fold_ed()
+        self._require_fold()
         self._ed_fwd(self.notes)
         ops.softmax_ce(self.logits, self.emot_idx, self.emo, self.dlogits, self.lambda_emo)
         self._ed_bwd(self.dnotes if self.ed_mode == "notes" else None)

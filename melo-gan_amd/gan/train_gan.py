@@ -58,14 +58,29 @@ def load_ed_checkpoint(eng: GanEngine, path: str):
     print(f"[INFO] Loading pre-trained Emotion Discriminator from {path}")
     ckpt = torch.load(path, map_location="cpu")
     sd = ckpt["model"] if "model" in ckpt else ckpt
+    # strict=False semantics: a key the checkpoint lacks keeps its initial value (reported, not silent -- a spectral-norm
+    # triple with one part missing counts as missing); a key of the wrong shape raises, as load_state_dict does
+    missing, bad = [], []
     for k in eng.ED.spec:
         w = spectral_norm_weight(sd, k)
-        if w is not None and tuple(w.shape) == tuple(eng.ED.spec[k]):
+        if w is None:
+            missing.append(k)
+        elif tuple(w.shape) != tuple(eng.ED.spec[k]):
+            bad.append(f"{k}: checkpoint {tuple(w.shape)} vs model {tuple(eng.ED.spec[k])}")
+        else:
             eng.ED.p[k].copy_(w.float())
     for k in eng.EDbuf:
-        if k in sd:
+        if k not in sd:
+            missing.append(k)
+        elif tuple(sd[k].shape) != tuple(eng.EDbuf[k].shape):
+            bad.append(f"{k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(eng.EDbuf[k].shape)}")
+        else:
             eng.EDbuf[k].copy_(sd[k].float())
-    eng._ed_folded = False
+    if bad:
+        raise RuntimeError("Error(s) in loading state_dict for EmotionDiscriminator: size mismatch for " + "; ".join(bad))
+    if missing:
+        print(f"[WARN] ED checkpoint {path} lacks {len(missing)} key(s), left at their initial values: {', '.join(missing)}")
+    eng.fold_ed()          # derived scale / shift / re-laid weights: eagerly, outside any graph
     return True
 
 
@@ -115,18 +130,53 @@ def adam_state_dict(fp, lr: float, betas, eps: float = 1e-8, weight_decay: float
 def load_adam_state_dict(fp, sd: dict):
     """Inverse of adam_state_dict (resume): fills the flat moment buffers, the step counter and the running beta powers
     the update kernel keeps beside it (state = [step, beta1^step, beta2^step, -])."""
+    state = sd["state"]
+    if not state:                       # an optimiser that never stepped: fresh moments
+        fp.m.zero_(); fp.v.zero_(); fp.state.zero_()
+        return
+    if len(state) != len(fp.spec):
+        raise ValueError(f"optimizer state_dict has {len(state)} parameter entries, this optimiser has {len(fp.spec)}")
+    steps = set()
+    for i, k in enumerate(fp.spec):
+        if i not in state:
+            raise ValueError(f"optimizer state_dict lacks entry {i} ({k})")
+        st = state[i]
+        for part in ("exp_avg", "exp_avg_sq"):
+            if tuple(st[part].shape) != tuple(fp.spec[k]):
+                raise ValueError(f"optimizer state_dict entry {i} ({k}).{part}: shape {tuple(st[part].shape)} != {tuple(fp.spec[k])}")
+        steps.add(float(st["step"]))
+    if len(steps) != 1:
+        raise ValueError(f"optimizer state_dict: per-parameter step counts differ ({sorted(steps)}); the flat optimiser keeps one")
     for i, k in enumerate(fp.spec):
         off, n = fp.offsets[k]
-        st = sd["state"][i]
-        fp.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(fp.m.device))
-        fp.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(fp.v.device))
-    if sd["state"]:
-        step = float(sd["state"][0]["step"])
-        b1, b2 = sd["param_groups"][0]["betas"]
-        fp.state[0], fp.state[1], fp.state[2] = step, float(b1) ** step, float(b2) ** step
+        fp.m[off:off + n].copy_(state[i]["exp_avg"].reshape(-1).to(fp.m.device))
+        fp.v[off:off + n].copy_(state[i]["exp_avg_sq"].reshape(-1).to(fp.v.device))
+    step = steps.pop()
+    b1, b2 = sd["param_groups"][0]["betas"]
+    fp.state[0], fp.state[1], fp.state[2] = step, float(b1) ** step, float(b2) ** step
 
 
-def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: bool = True):
+def resume_checkpoint(eng: GanEngine, path: str) -> int:
+    """Continue from a gan_epochNNNN.pth written by save_checkpoint (or by the reference trainer, train_gan.py:267-276):
+    G (with its BatchNorm buffers), D, E_num, both optimisers.  Returns the epoch the checkpoint was written after."""
+    ck = torch.load(path, map_location="cpu")
+    for key in ("G", "D", "E_num", "opt_G", "opt_D"):
+        if key not in ck:
+            raise KeyError(f"{path}: not a full training checkpoint (no '{key}')")
+    eng.GE.load({**{"G." + k: v for k, v in ck["G"].items()}, **{"E." + k: v for k, v in ck["E_num"].items()}})
+    eng.D.load(ck["D"])
+    for k in eng.Gbuf:
+        eng.Gbuf[k].copy_(ck["G"][k].float())
+    nbt = [v for k, v in ck["G"].items() if k.endswith("num_batches_tracked")]
+    if nbt:
+        eng.num_batches_tracked = int(nbt[0])
+    load_adam_state_dict(eng.GE, ck["opt_G"])
+    load_adam_state_dict(eng.D, ck["opt_D"])
+    eng.params_changed()
+    return int(ck.get("epoch") or 0)
+
+
+def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: bool = True, resume: str = None):
     cfg = C.with_gan_defaults(cfg, require=not synthetic)
     seed_everything(cfg.get("SEED", 42))
     if not torch.cuda.is_available():
@@ -156,6 +206,9 @@ def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: 
     eng = GanEngine(cfg, ed_cfg, device, B, ed_dtype=str(cfg.get("ED_DTYPE", "fp32")))
     eng.init_weights(cfg.get("SEED", 42))
     load_ed_checkpoint(eng, ed_ckpt)
+    start_epoch = resume_checkpoint(eng, resume) if resume else 0
+    if resume:
+        log(f"[INFO] Resumed from {resume} (epoch {start_epoch})")
     dp = DataParallel(eng, world, dist)
     dp.broadcast_params()
     eng.seed(cfg.get("SEED", 42) + rank)            # rank-offset Philox key: every shard draws its own noise
@@ -167,7 +220,7 @@ def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: 
     shuffle_gen = torch.Generator().manual_seed(cfg.get("SEED", 42))
     log("Starting WGAN-GP Training with Emotion Guidance...")
     with torch.cuda.stream(eng.stream):
-        for epoch in range(1, cfg["EPOCHS"] + 1):
+        for epoch in range(start_epoch + 1, cfg["EPOCHS"] + 1):
             sums.zero_()
             steps = 0
             # every rank walks the same shuffled order and takes the batches rank, rank + world, ...; a trailing
@@ -217,12 +270,13 @@ def main(argv=None):
     parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic rolls instead of TRAIN_SPLIT")
     parser.add_argument("--epochs", type=int, default=None, help="override EPOCHS")
     parser.add_argument("--no-graph", action="store_true")
+    parser.add_argument("--resume", type=str, default=None, help="gan_epochNNNN.pth to continue from (G, D, E_num, opt_G, opt_D)")
     args = parser.parse_args(argv)
     cfg = C.load_config(args.config)
     ed_cfg = C.load_config(args.ed_config)
     if args.epochs is not None:
         cfg["EPOCHS"] = args.epochs
-    train(cfg, ed_cfg, args.ed_ckpt, args.synthetic, not args.no_graph)
+    train(cfg, ed_cfg, args.ed_ckpt, args.synthetic, not args.no_graph, args.resume)
 
 
 if __name__ == "__main__":

@@ -64,6 +64,33 @@ def test_optimizer_checkpoint_is_a_torch_adam_state_dict():
     assert float(fp2.state[0]) == 7.0 and abs(float(fp2.state[1]) - 0.5 ** 7) < 1e-15 and abs(float(fp2.state[2]) - 0.9 ** 7) < 1e-15
 
 
+def test_optimizer_state_dict_is_validated_on_load():
+    """A partial or mismatched optimiser checkpoint must fail with a message, not restore a wrong step silently."""
+    import pytest
+    import torch
+    from collections import OrderedDict
+    from melo_gan_amd.gan.engine import FlatParams
+    from melo_gan_amd.gan.train_gan import adam_state_dict, load_adam_state_dict
+    spec = OrderedDict([("a.weight", (3, 4)), ("a.bias", (3,))])
+    fp = FlatParams(spec, "cpu")
+    fp.state[0] = 3.0
+    good = adam_state_dict(fp, 1e-4, (0.5, 0.9))
+    sd = {"state": {0: good["state"][0]}, "param_groups": good["param_groups"]}
+    with pytest.raises(ValueError, match="parameter entries"):
+        load_adam_state_dict(fp, sd)
+    sd = adam_state_dict(fp, 1e-4, (0.5, 0.9))
+    sd["state"][1]["exp_avg"] = torch.zeros(4)
+    with pytest.raises(ValueError, match="shape"):
+        load_adam_state_dict(fp, sd)
+    sd = adam_state_dict(fp, 1e-4, (0.5, 0.9))
+    sd["state"][1]["step"] = torch.tensor(9.0)
+    with pytest.raises(ValueError, match="step counts differ"):
+        load_adam_state_dict(fp, sd)
+    fp.m.fill_(1.0)
+    load_adam_state_dict(fp, {"state": {}, "param_groups": good["param_groups"]})       # never stepped: fresh moments
+    assert float(fp.m.abs().sum()) == 0.0 and float(fp.state[0]) == 0.0
+
+
 def test_spectral_norm_checkpoint_weights_fold_at_load():
     """A frozen emotion discriminator trained with use_spectral_norm (ed_model.py:29-32): the weight its eval-mode forward
     uses is weight_orig / (u^T W v); train_gan.spectral_norm_weight reproduces what torch's wrapper computes."""

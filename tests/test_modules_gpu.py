@@ -110,3 +110,62 @@ def test_trainer_cli_smoke(tmp_path):
     assert int(final["G"]["decoder.deconv.1.num_batches_tracked"]) > 0
     for v in final["G"].values():
         assert torch.isfinite(v.float()).all()
+
+
+def test_resume_continues_from_a_full_checkpoint(tmp_path):
+    """--resume: G (+ BatchNorm buffers), D, E_num and both optimisers come back from gan_epochNNNN.pth; the derived copies
+    (WQ-layout weights, folded emotion discriminator) are refreshed; training continues at the next epoch."""
+    import yaml
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.gan import train_gan
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "config", "gan_config.yaml")))
+    cfg.update(EPOCHS=1, BATCH_SIZE=4, MAX_NOTES=32, SAVE_FREQ=1, CRITIC_ITERS=2,
+               CHECKPOINT_DIR=str(tmp_path / "ck"), LOG_DIR=str(tmp_path / "log"), SAMPLE_DIR=str(tmp_path / "s"))
+    ed = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "config", "ed_config.yaml")))
+    e1 = train_gan.train(dict(cfg), dict(ed), str(tmp_path / "none.pth"), synthetic=20)
+    ck = str(tmp_path / "ck" / "gan_epoch0001.pth")
+    from melo_gan_amd.gan.engine import GanEngine
+    from melo_gan_amd.gan import config as Cfg
+    e2 = GanEngine(Cfg.with_gan_defaults(dict(cfg), require=False), dict(ed), "cuda", 4)
+    e2.init_weights(7)
+    assert train_gan.resume_checkpoint(e2, ck) == 1
+    for a, b in ((e1.GE, e2.GE), (e1.D, e2.D)):
+        assert torch.equal(a.data, b.data) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v)
+        assert float(a.state[0]) == float(b.state[0]) > 0 and abs(float(a.state[1]) - float(b.state[1])) < 1e-12
+    for k in e1.Gbuf:
+        assert torch.equal(e1.Gbuf[k], e2.Gbuf[k])
+    for k in e1.wq:
+        assert torch.equal(e1.wq[k], e2.wq[k]), k
+    assert e2.num_batches_tracked == e1.num_batches_tracked
+    cfg2 = dict(cfg, EPOCHS=2)
+    e3 = train_gan.train(cfg2, dict(ed), str(tmp_path / "none.pth"), synthetic=20, resume=ck)
+    assert os.path.exists(tmp_path / "ck" / "gan_epoch0002.pth")
+    assert float(e3.D.state[0]) > float(e1.D.state[0])
+    with pytest.raises(KeyError):
+        train_gan.resume_checkpoint(e2, str(tmp_path / "ck" / "gan_final.pth"))
+
+
+def test_ed_checkpoint_shape_mismatch_raises_and_missing_keys_are_reported(tmp_path, capsys):
+    """load_state_dict(strict=False) semantics (reference train_gan.py:121-128): missing keys are tolerated but named, a size
+    mismatch raises; an incomplete spectral-norm triple counts as missing."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.gan import train_gan
+    from melo_gan_amd.gan.engine import GanEngine
+    eng = GanEngine(O.default_gan_cfg(4, 32, 4), O.default_ed_cfg(4), "cuda", 4)
+    eng.init_weights(0)
+    sd = {**{k: v.cpu().clone() for k, v in eng.ED.p.items()}, **{k: v.cpu().clone() for k, v in eng.EDbuf.items()}}
+    w = sd.pop("classifier.head.weight")
+    sd["classifier.head.weight_orig"], sd["classifier.head.weight_u"] = w, torch.ones(w.shape[0])       # no _v: incomplete triple
+    sd["encoder.project.bias"] = sd["encoder.project.bias"] + 1.0
+    p = str(tmp_path / "ed.pth")
+    torch.save({"model": sd}, p)
+    before = eng.ED.p["classifier.head.weight"].clone()
+    assert train_gan.load_ed_checkpoint(eng, p)
+    out = capsys.readouterr().out
+    assert "classifier.head.weight" in out and "lacks 1 key" in out
+    assert torch.equal(eng.ED.p["classifier.head.weight"], before)
+    torch.testing.assert_close(eng.ED.p["encoder.project.bias"].cpu(), sd["encoder.project.bias"])
+    sd["encoder.conv.1.net.0.weight"] = torch.zeros(3, 3, 3)
+    torch.save({"model": sd}, p)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        train_gan.load_ed_checkpoint(eng, p)
