@@ -108,12 +108,13 @@ int mg_conv16_supported(int B, int Tin, int Cin, int N, int transposed, int Tout
 int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
               long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream);
 /* The same launch that ALSO leaves per-column partial statistics of the values v it stores, so that the train-mode
- * BatchNorm that follows needs no reduction pass of its own:
- *   part[(2*tile + wave_row)][0][n] = sum_rows v[row, n],   [1][n] = sum v*v
- * part: 2 * part_rows * N floats; part_rows and the batch rows a tile spans from mg_conv16_plan (a caller that stacks
+ * BatchNorm that follows needs no reduction pass of its own: for every (tile, wave row) p and column n
+ *   part[p][0][n] = sum_rows v[row, n],   [1][n] = sum_rows (v - mean_p)^2 about that wave's OWN mean,   [2][n] = rows summed
+ * (combined by the parallel-variance rule in fp64: nothing is formed as E[x^2] - mean^2).
+ * part: 3 * part_rows * N floats; part_rows and the batch rows a tile spans from mg_conv16_plan (a caller that stacks
  * several BatchNorm groups along the batch needs the group size to be a multiple of batch_rows_per_tile).
- * mg_bn_train_fwd_parts finishes the statistics (fixed order, fp64), moves the running ones and applies: the semantics of
- * mg_bn_train_fwd_groups (nn.BatchNorm1d training forward, src/gan/models.py:57-61) in two launches instead of three. */
+ * mg_bn_train_fwd_parts finishes the statistics (fixed order, fp64), moves the running ones and applies, all in ONE launch:
+ * the semantics of mg_bn_train_fwd_groups (nn.BatchNorm1d training forward, src/gan/models.py:57-61). */
 int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_rows_per_tile, int* part_rows, int* tile_rows);
 int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                     long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream);
@@ -123,9 +124,69 @@ int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, i
 int mg_conv16_poolable(int B, int Tin, int Cin, int N);
 int mg_conv16_pool(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, long xbs, long ybs,
                    const mg_epilogue* epi, float* pool, float pool_scale, mg_stream_t stream);
+/* One launch with any of the riders: statistics (part), temporal mean (pool), the permuted output order
+ *   y_perm: y[b*ybs + n*Tout + tout] -- the (B, N*Tout) order behind the reference's `view(B, 256, L)` (src/gan/models.py:70),
+ *           so the data-gradient of the first deconvolution lands in decoder.pre.2's output order with no transpose launch
+ *           (zout / gref / emul keep the dense (b, tout, n) index);
+ * and the gradient penalty's interpolate (src/gan/utils.py:76-79): for batch rows b < mix_rows ALSO
+ *   mix_out[i] = mix_alpha[b] * mix_real[i] + (1 - mix_alpha[b]) * y[i]   at the element's y index i. */
+typedef struct mg_conv16_extra {
+    float* part;
+    float* pool;
+    float pool_scale;
+    int y_perm;
+    const float* mix_real;
+    const float* mix_alpha;
+    float* mix_out;
+    int mix_rows;
+} mg_conv16_extra;
+int mg_conv16_ex(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+                 long xbs, long ybs, const mg_epilogue* epi, const mg_conv16_extra* extra, mg_stream_t stream);
 int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups, const float* z, float* a, long R, int C,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                           float eps, float* save_mean, float* save_invstd, int act, mg_stream_t stream);
+
+/* ---- row chains (csrc/row_chain.hip): a sample's small layer stack as ONE launch -- one workgroup walks one row through
+ *      an op list with the activations in LDS vector slots (MG_CHAIN_SLOTS slots of MG_CHAIN_MAX_VEC floats).  Used for the
+ *      numeric encoder (LayerNorm + 3 Linear, src/gan/feature_encoder.py:16-45) forward and data-gradient, the emotion
+ *      classifier's tail (ed_model.py:61,86-95,147-165: project, MLP, head, cross-entropy and their data-gradients) and the
+ *      critic's tail (src/gan/models.py:149-169: fc, scoring head and their data-gradients).  Row r of every global operand
+ *      is at ptr + r * ld.  Ops (fields not named are ignored):
+ *   LOAD       slot b [0,n0) (+= if i0) p0 row (r % i1 if i1 > 0)
+ *   STORE      q0 row <- slot a [0,n0)
+ *   MEAN_T     slot b [0,n0) = mean over t < i0 of p0[(r*i0 + t)*ld0 + c]  (AdaptiveAvgPool1d(1) of a (rows, i0, ld0) tensor); q0 rows <- it
+ *   LAYERNORM  slot b = LN(slot a [0,n0<=64)) * p0 + p1, eps f0; q0 rows <- xhat, q1 rows <- output (optional)
+ *   LIN_FWD    slot b [0,n1) = act(slot a [0,n0) W^T + p1) * p2 row;  W(n,k) = p0[n*ld0 + k];  q0 rows <- pre-activation,
+ *              q1 rows <- output (optional)                                              (nn.Linear forward + act + dropout mask)
+ *   LIN_DGRAD  slot b [0,n1) = (slot a [0,n0) W) * act'(p1 row) * p2 row;  W(o,i) = p0[o*ld0 + i];  q1 rows <- output
+ *   SOFTMAX_CE slot a = logits [0,n0<=32), t0 = int64 targets: q0[r] = -log softmax[target];  slot b = f0 * (softmax - onehot)
+ *              (F.cross_entropy forward + backward per row; an out-of-range target poisons the row with NaN)
+ *   DHEAD      critic head on slot a = f [0,n0): q0[r] = f . w[0,n0) + emb row (r % i1) . w[n0, n0+n1) + p1[0], w = p0, emb = p2;
+ *              slot b = p3[r] * w[0,n0) * lrelu'(f);  q1 rows <- p3[r] * w[n0, n0+n1)       (src/gan/models.py:160-169 + backward)
+ */
+#define MG_CHAIN_MAX_OPS 16
+#define MG_CHAIN_SLOTS 6
+#define MG_CHAIN_MAX_VEC 512
+enum { MG_CH_LOAD = 1, MG_CH_STORE = 2, MG_CH_LAYERNORM = 3, MG_CH_LIN_FWD = 4, MG_CH_LIN_DGRAD = 5, MG_CH_SOFTMAX_CE = 6,
+       MG_CH_DHEAD = 7, MG_CH_MEAN_T = 8 };
+typedef struct mg_chain_op {
+    int kind;
+    int a, b;
+    int n0, n1;
+    int act;
+    int i0, i1;
+    float f0;
+    const float* p0; long ld0;
+    const float* p1; long ld1;
+    const float* p2; long ld2;
+    const float* p3; long ld3;
+    float* q0; long lq0;
+    float* q1; long lq1;
+    const int64_t* t0;
+} mg_chain_op;
+int mg_row_chain(const mg_chain_op* ops, int n_ops, int rows, mg_stream_t stream);
+/* out[0] = scale * mean(src[0..n)) (one block): the loss scalar behind a chain's per-row cross-entropy terms */
+int mg_mean_scaled(const float* src, float* out, int n, float scale, mg_stream_t stream);
 
 /* ---- skinny GEMM for nn.Linear forward / data-gradient with few rows (M = batch) ----
  *   y[M,N] = EPI( x[M,K] @ W^T ),  W(n,c) = w[n*w_sn + c*w_sc], one of the strides must be 1:
@@ -135,6 +196,12 @@ int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups
 size_t mg_linear_workspace_bytes(int M, int N, int K);
 int mg_linear(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, int w_sc,
               const mg_epilogue* epi, void* work, size_t work_bytes, mg_stream_t stream);
+/* The same with the OUTPUT COLUMNS PERMUTED: column n' of y is weight row (n' % C) * perm_L + n' / C, C = N / perm_L (bias,
+ * scale, gscale follow the weight row; zout / gref / emul the stored order): y comes out as the channels-last (M, perm_L, C)
+ * tensor the reference reaches by `view(B, 256, L)` + permute(0, 2, 1) on the way into the first ConvTranspose1d
+ * (src/gan/models.py:70-73) -- no transpose launch.  perm_L = 0: mg_linear. */
+int mg_linear_perm(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, int w_sc,
+                   const mg_epilogue* epi, int perm_L, void* work, size_t work_bytes, mg_stream_t stream);
 
 /* Which instantiation of conv_wgemm_kernel<S,K,TR2,TM,TN> a call launches: TM*10+TN (22: 128x128 tile,
  * 12: 64x128, 11: 64x64).  m_rows = B*Tout (gather) or B*Tin (scatter2).  Lets a profiler label
@@ -297,6 +364,15 @@ int mg_wgan_d_loss_gp(const float* s, const float* norms, float lambda_gp, float
 int mg_softmax_ce(const float* logits, const int64_t* target, float* loss, float* dlogits,
                   float coef, int B, int C, mg_stream_t stream);
 /* out[0] = -mean(s[0:B]) */
+/* mg_dhead_wgrad with the critic's loss scalars riding in the same launch (one extra block): mg_wgan_d_loss_gp's outputs
+ * (loss_out = {loss_d, mean real, mean fake}, gp_out = mean((norm-1)^2)); loss_out = NULL: mg_dhead_wgrad. */
+int mg_dhead_wgrad_loss(const float* ds, const float* f, const float* emb, const float* gf, float* dw, float* dbias,
+                        int nb, int ng, int Be, int F, int E, const float* s, const float* norms, float lambda_gp,
+                        float* loss_out, float* gp_out, int nb_loss, mg_stream_t stream);
+/* mg_meanT_bwd with a scalar mean riding in the same launch (one extra block): mean_out[0] = mean_scale * mean(mean_src[0..n))
+ * -- the generator's adversarial loss -mean(D(fake)), src/gan/train_gan.py:224.  mean_out = NULL: mg_meanT_bwd. */
+int mg_meanT_bwd_mean(const float* dh, float* dz, int B, int T, int C, const float* gref, int gact, const float* gscale,
+                      const float* mean_src, float* mean_out, int mean_n, float mean_scale, mg_stream_t stream);
 int mg_neg_mean(const float* s, float* out, int B, mg_stream_t stream);
 
 /* ---- elementwise helpers ---- */
@@ -327,6 +403,7 @@ typedef struct mg_stage_job {
     long row_bytes;
     long src_rows;
     long dst_pitch;     /* bytes between destination rows; 0 = row_bytes */
+    long rows;          /* rows of THIS job (<= n_rows); 0 = n_rows */
 } mg_stage_job;
 int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t stream);
 

@@ -23,8 +23,23 @@ class EpilogueBf16(C.Structure):
                 ("accumulate", i32)]
 
 
+class Conv16Extra(C.Structure):
+    _fields_ = [("part", vp), ("pool", vp), ("pool_scale", f32), ("y_perm", i32), ("mix_real", vp), ("mix_alpha", vp),
+                ("mix_out", vp), ("mix_rows", i32)]
+
+
+class ChainOp(C.Structure):
+    _fields_ = [("kind", i32), ("a", i32), ("b", i32), ("n0", i32), ("n1", i32), ("act", i32), ("i0", i32), ("i1", i32), ("f0", f32),
+                ("p0", vp), ("ld0", i64), ("p1", vp), ("ld1", i64), ("p2", vp), ("ld2", i64), ("p3", vp), ("ld3", i64),
+                ("q0", vp), ("lq0", i64), ("q1", vp), ("lq1", i64), ("t0", vp)]
+
+
+CH_LOAD, CH_STORE, CH_LAYERNORM, CH_LIN_FWD, CH_LIN_DGRAD, CH_SOFTMAX_CE, CH_DHEAD, CH_MEAN_T = 1, 2, 3, 4, 5, 6, 7, 8
+CHAIN_MAX_OPS, CHAIN_SLOTS, CHAIN_MAX_VEC = 16, 6, 512
+
+
 class StageJob(C.Structure):
-    _fields_ = [("src", vp), ("dst", vp), ("idx", vp), ("row_bytes", i64), ("src_rows", i64), ("dst_pitch", i64)]
+    _fields_ = [("src", vp), ("dst", vp), ("idx", vp), ("row_bytes", i64), ("src_rows", i64), ("dst_pitch", i64), ("rows", i64)]
 
 
 MAX_STAGE_JOBS = 8
@@ -56,11 +71,13 @@ SIGNATURES = {
     "mg_conv16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp]),
     "mg_conv16_plan": (i32, [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "mg_conv16_stats": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, vp]),
+    "mg_conv16_ex": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), C.POINTER(Conv16Extra), vp]),
     "mg_conv16_poolable": (i32, [i32, i32, i32, i32]),
     "mg_conv16_pool": (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, f32, vp]),
     "mg_bn_train_fwd_parts": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp]),
     "mg_linear_workspace_bytes": (sz, [i32, i32, i32]),
     "mg_linear": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), vp, sz, vp]),
+    "mg_linear_perm": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(Epilogue), i32, vp, sz, vp]),
     "mg_conv_tile_config": (i32, [i64, i32, i32]),
     "mg_conv_thin_route": (i32, [vp, i64, i32, i32, i32, i32, i32]),
     "mg_wb_relayout": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -88,6 +105,10 @@ SIGNATURES = {
     "mg_dhead_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mg_dhead_fwd_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mg_dhead_wgrad": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mg_dhead_wgrad_loss": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
+    "mg_meanT_bwd_mean": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, i32, f32, vp]),
+    "mg_row_chain": (i32, [vp, i32, i32, vp]),
+    "mg_mean_scaled": (i32, [vp, vp, i32, f32, vp]),
     "mg_gp_interp": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "mg_gp_penalty": (i32, [vp, vp, vp, vp, f32, i32, i64, vp]),
     "mg_wgan_d_loss": (i32, [vp, vp, f32, vp, i32, vp]),

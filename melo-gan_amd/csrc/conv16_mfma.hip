@@ -45,6 +45,17 @@ struct Conv16P {
     // time axis (host checked: one 16*RT-row wave tile per sample) -- the pooling launch and its dependent boundary disappear
     float* pool;
     float pool_scale;
+    // y_perm: store y[b*ybs + n*Tout + tout] instead of [b*ybs + tout*N + n] -- the (B, N*Tout) order a following Linear's
+    // input view has (src/gan/models.py:70 `view(B, 256, L)` read backwards by the data-gradient); gref / zout / emul keep
+    // the dense (b, tout, n) index.  Replaces a transpose launch.
+    int y_perm;
+    // mix: for output batch rows b < mix_rows ALSO write mix_out[i] = alpha[b] * mix_real[i] + (1 - alpha[b]) * v at the
+    // element's y index i -- the gradient penalty's interpolate (src/gan/utils.py:76-79) riding in the launch that
+    // produces the fake batch: x_hat needs no pass of its own
+    const float* mix_real;
+    const float* mix_alpha;
+    float* mix_out;
+    int mix_rows;
 };
 
 constexpr int K5 = 5;
@@ -237,7 +248,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     const float bias = E.bias ? E.bias[n] : 0.f;
     const float scale = E.scale ? E.scale[n] : 1.f, shift = E.scale ? E.shift[n] : 0.f;
     const float gscale = E.gscale ? E.gscale[n] : 1.f;
-    float st1 = 0.f, st2 = 0.f;
+    float st1 = 0.f, cnt = 0.f;
+    const bool want_stats = p.part || p.pool;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -245,7 +257,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
             f32x4 a = acc[ph][rt][0];
             if constexpr (KA == 2) a += acc[ph][rt][1];
             unsigned di[4], yi[4];
-            bool ok[4];
+            bool ok[4], mixrow[4];
+            int brow[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int im = (wm * RT + rt) * 16 + 4 * kq + r;
@@ -253,8 +266,10 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
                 const int b = b0 + seg, t = t0 + tl;
                 const int tout = TR2 ? 2 * t + ph : t;
                 di[r] = (unsigned)((b * p.Tout + tout) * p.N + n);
-                yi[r] = (unsigned)(b * (int)p.ybs + tout * p.N + n);
+                yi[r] = (unsigned)(b * (int)p.ybs + (p.y_perm ? n * p.Tout + tout : tout * p.N + n));
                 ok[r] = b < p.B && t < p.Tm && tout < p.Tout;
+                mixrow[r] = ok[r] && b < p.mix_rows;
+                brow[r] = mixrow[r] ? b : 0;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = (a[r] + bias) * scale + shift;
@@ -305,13 +320,14 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] *= gscale;
-            if (p.part || p.pool) {
+            if (want_stats) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (ok[r]) {
                         st1 += a[r];
-                        st2 += a[r] * a[r];
+                        cnt += 1.f;
                     }
+                acc[ph][rt][0] = a;        // kept for the centred second pass below
             }
             if (E.accumulate) {
                 float g[4];
@@ -323,16 +339,49 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (ok[r]) p.y[yi[r]] = a[r];
+            if (p.mix_out) {
+                float rv[4], al[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rv[r] = p.mix_real[mixrow[r] ? yi[r] : 0u];
+                    al[r] = p.mix_alpha[brow[r]];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (mixrow[r]) p.mix_out[yi[r]] = fmaf(al[r], rv[r], (1.f - al[r]) * a[r]);
+            }
         }
-    if (p.part || p.pool) {        // the four lanes of a column (row groups kq = 0..3) -> one partial per wave and column
+    if (want_stats) {        // the four lanes of a column (row groups kq = 0..3) -> one partial per wave and column
         st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
-        st2 += __shfl_xor(st2, 16, 64); st2 += __shfl_xor(st2, 32, 64);
-        if (kq == 0 && p.part) {
-            float* dst = p.part + (long)(2 * blockIdx.x + wm) * 2 * p.N + n;
-            dst[0] = st1;
-            dst[p.N] = st2;
-        }
         if (kq == 0 && p.pool && 2 * (int)blockIdx.x + wm < p.B) p.pool[(long)(2 * blockIdx.x + wm) * p.N + n] = st1 * p.pool_scale;
+        if (p.part) {
+            // Sum of squares about the WAVE's own mean (its <= 64 values are still in registers): the combining kernel adds
+            // the partials by the parallel-variance rule in fp64, so nothing is ever formed as E[x^2] - mean^2 -- a channel
+            // whose |mean| is far above its deviation keeps its variance digits.
+            cnt += __shfl_xor(cnt, 16, 64); cnt += __shfl_xor(cnt, 32, 64);
+            const float mw = cnt > 0.f ? st1 / cnt : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int im = (wm * RT + rt) * 16 + 4 * kq + r;
+                        const int seg = im >> p.tt_log2, tl = im & (TT - 1);
+                        const int b = b0 + seg, t = t0 + tl;
+                        const int tout = TR2 ? 2 * t + ph : t;
+                        const float d = acc[ph][rt][0][r] - mw;
+                        if (b < p.B && t < p.Tm && tout < p.Tout) m2 += d * d;
+                    }
+            m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
+            if (kq == 0) {
+                float* dst = p.part + (long)(2 * blockIdx.x + wm) * 3 * p.N + n;
+                dst[0] = st1;
+                dst[p.N] = m2;
+                dst[2 * p.N] = cnt;
+            }
+        }
     }
 }
 
@@ -435,10 +484,8 @@ extern "C" int mg_conv16_plan(int B, int Tin, int N, int transposed, int* batch_
     return MG_OK;
 }
 
-extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
-                               long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream);
 static int conv16_launch(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
-                         long xbs, long ybs, const mg_epilogue* epi, float* part, float* pool, float pool_scale, mg_stream_t stream);
+                         long xbs, long ybs, const mg_epilogue* epi, const mg_conv16_extra& ex, mg_stream_t stream);
 
 // 1 if a launch of this shape can also write the temporal mean of its output: gather form, every sample's time axis is
 // exactly one wave's rows of a tile (Tout = 32 with 64-row tiles, 16 with 32-row tiles)
@@ -453,23 +500,41 @@ extern "C" int mg_conv16_pool(const float* x, const float* wq, float* y, int B, 
     MG_CHECK_ARG(pool != nullptr, "mg_conv16_pool: null pool tensor");
     MG_CHECK_ARG(mg_conv16_poolable(B, Tin, Cin, N), "mg_conv16_pool: shape B=%d Tin=%d Cin=%d N=%d is not poolable", B, Tin, Cin, N);
     MG_CHECK_ARG(!(epi && epi->accumulate), "mg_conv16_pool: the mean of an accumulating launch is not defined");
-    return conv16_launch(x, wq, y, B, Tin, Cin, N, 0, 0, xbs, ybs, epi, nullptr, pool, pool_scale, stream);
+    mg_conv16_extra ex{};
+    ex.pool = pool;
+    ex.pool_scale = pool_scale;
+    return conv16_launch(x, wq, y, B, Tin, Cin, N, 0, 0, xbs, ybs, epi, ex, stream);
 }
 
 extern "C" int mg_conv16(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                          long xbs, long ybs, const mg_epilogue* epi, mg_stream_t stream) {
-    return mg_conv16_stats(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, nullptr, stream);
+    return conv16_launch(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, mg_conv16_extra{}, stream);
 }
 
 extern "C" int mg_conv16_stats(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                                long xbs, long ybs, const mg_epilogue* epi, float* part, mg_stream_t stream) {
-    return conv16_launch(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, part, nullptr, 0.f, stream);
+    mg_conv16_extra ex{};
+    ex.part = part;
+    return conv16_launch(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, ex, stream);
+}
+
+extern "C" int mg_conv16_ex(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
+                            long xbs, long ybs, const mg_epilogue* epi, const mg_conv16_extra* extra, mg_stream_t stream) {
+    return conv16_launch(x, wq, y, B, Tin, Cin, N, transposed, Tout, xbs, ybs, epi, extra ? *extra : mg_conv16_extra{}, stream);
 }
 
 static int conv16_launch(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
-                         long xbs, long ybs, const mg_epilogue* epi, float* part, float* pool, float pool_scale, mg_stream_t stream) {
+                         long xbs, long ybs, const mg_epilogue* epi, const mg_conv16_extra& ex, mg_stream_t stream) {
+    float* const part = ex.part;
+    float* const pool = ex.pool;
+    const float pool_scale = ex.pool_scale;
     MG_CHECK_ARG(x && wq && y, "mg_conv16: null tensor");
     MG_CHECK_ARG(!(part && epi && epi->accumulate), "mg_conv16: statistics of an accumulating launch are not defined");
+    MG_CHECK_ARG(!pool || (!transposed && mg_conv16_poolable(B, Tin, Cin, N)), "mg_conv16: shape is not poolable");
+    MG_CHECK_ARG(!ex.mix_out || (ex.mix_real && ex.mix_alpha && ex.mix_rows > 0 && ex.mix_rows <= B && !ex.y_perm),
+                 "mg_conv16: mix needs real, alpha, 0 < rows <= B and the plain output order");
+    MG_CHECK_ARG(!ex.y_perm || (ybs == 0 || ybs == (long)N * (transposed ? Tout : (Tin + 4 - K5) / 2 + 1)),
+                 "mg_conv16: the permuted output order needs a dense y");
     const int Tm = transposed ? Tin : (Tin + 4 - K5) / 2 + 1;
     if (!transposed) Tout = Tm;
     MG_CHECK_ARG(mg_conv16_supported(B, Tin, Cin, N, transposed, Tout), "mg_conv16: unsupported shape B=%d Tin=%d Cin=%d N=%d", B, Tin, Cin, N);
@@ -489,6 +554,9 @@ static int conv16_launch(const float* x, const float* wq, float* y, int B, int T
     p.part = part;
     p.pool = pool;
     p.pool_scale = pool_scale;
+    p.y_perm = ex.y_perm ? 1 : 0;
+    p.mix_real = ex.mix_real; p.mix_alpha = ex.mix_alpha; p.mix_out = ex.mix_out;
+    p.mix_rows = ex.mix_out ? ex.mix_rows : 0;
     hipStream_t s = (hipStream_t)stream;
     const int rt = pick_rt((long)B * Tm, N);
     int rc;

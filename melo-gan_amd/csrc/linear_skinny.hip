@@ -22,8 +22,13 @@ struct LinP {
     int ksplit;
     int gx, gy;       // row / column tiles
     int kw;           // K range per wave (multiple of 8)
+    // perm_L > 0: output column n' is weight row (n' % perm_C) * perm_L + n' / perm_C (perm_C = N / perm_L): the output
+    // comes out as (M, perm_L, perm_C) -- the channels-last (B, L, C) tensor the reference reaches by view(B, C, L) +
+    // permute (src/gan/models.py:70,73) -- with coalesced stores; a lane reads its own weight row anyway
+    int perm_L, perm_C;
     mg_epilogue e;
 };
+__device__ __forceinline__ int wrow(const LinP& p, int n) { return p.perm_L ? (n % p.perm_C) * p.perm_L + n / p.perm_C : n; }
 
 constexpr int UNR = 8;   // 8-deep k-steps per unrolled iteration: 8 float4 of A + 8 of B in flight
 constexpr int NW = 8;    // waves per workgroup (K-split inside the workgroup)
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(const LinP p) {
     const int bx = id % p.gx, byz = id / p.gx, by = byz % p.gy, bz = byz / p.gy;
     const int m0 = bx * 32, n0 = by * 32;
     const int row = min(m0 + i, p.M - 1);          // clamped: out-of-range rows/cols are computed but never stored
-    const int col = min(n0 + i, p.N - 1);
+    const int col = wrow(p, min(n0 + i, p.N - 1));
     const int kbeg = (bz * NW + wave) * p.kw;
     const int kend = min(kbeg + p.kw, p.K);
     const float* xr = p.x + (long)row * p.K;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(const LinP p) {
         const int rr = idx >> 5, cc = idx & 31;
         const int m = m0 + rr, n = n0 + cc;
         ok[q] = m < p.M && n < p.N;
-        nn[q] = ok[q] ? n : 0;
+        nn[q] = ok[q] ? wrow(p, n) : 0;
         di[q] = ok[q] ? (long)m * p.N + n : 0;
         float t = 0.f;
 #pragma unroll
@@ -155,12 +160,14 @@ __global__ __launch_bounds__(64 * NW) void linear_skinny_kernel(const LinP p) {
 }
 
 __global__ void linear_finish_kernel(const float* __restrict__ part, float* __restrict__ y, long mn, int N, int ksplit,
-                                     const mg_epilogue e) {
+                                     const mg_epilogue e, int perm_L, int perm_C) {
     const long di = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (di >= mn) return;
     float v = 0.f;
     for (int z = 0; z < ksplit; ++z) v += part[(long)z * mn + di];
-    v = mg_apply_epilogue(e, v, (int)(di % N), di);
+    int n = (int)(di % N);
+    if (perm_L) n = (n % perm_C) * perm_L + n / perm_C;
+    v = mg_apply_epilogue(e, v, n, di);
     if (e.accumulate) v += y[di];
     y[di] = v;
 }
@@ -180,14 +187,24 @@ extern "C" size_t mg_linear_workspace_bytes(int M, int N, int K) {
     return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
+extern "C" int mg_linear_perm(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, int w_sc,
+                              const mg_epilogue* epi, int perm_L, void* work, size_t work_bytes, mg_stream_t stream);
 extern "C" int mg_linear(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, int w_sc,
                          const mg_epilogue* epi, void* work, size_t work_bytes, mg_stream_t stream) {
+    return mg_linear_perm(x, w, y, M, K, N, w_sn, w_sc, epi, 0, work, work_bytes, stream);
+}
+
+extern "C" int mg_linear_perm(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, int w_sc,
+                              const mg_epilogue* epi, int perm_L, void* work, size_t work_bytes, mg_stream_t stream) {
     MG_CHECK_ARG(x && w && y, "mg_linear: null tensor");
+    MG_CHECK_ARG(perm_L >= 0 && (perm_L == 0 || N % perm_L == 0), "mg_linear_perm: perm_L must divide N");
     MG_CHECK_ARG(M > 0 && K > 0 && N > 0 && w_sn > 0 && w_sc > 0, "mg_linear: bad shape");
     MG_CHECK_ARG(w_sn == 1 || w_sc == 1, "mg_linear: one weight stride must be 1");
     LinP p{};
     p.x = x; p.w = w; p.y = y; p.M = M; p.K = K; p.N = N; p.w_sn = w_sn; p.w_sc = w_sc;
     p.e = epi ? *epi : mg_epilogue{};
+    p.perm_L = perm_L > 1 ? perm_L : 0;
+    p.perm_C = p.perm_L ? N / p.perm_L : 0;
     if (p.e.scale && !p.e.shift) { mg_set_error("mg_linear: scale without shift"); return MG_EARG; }
     p.ksplit = plan_ksplit(M, N, K);
     const bool kcontig = (w_sc == 1);
@@ -215,7 +232,7 @@ extern "C" int mg_linear(const float* x, const float* w, float* y, int M, int K,
     if (p.ksplit > 1) {
         const long mn = (long)M * N;
         hipLaunchKernelGGL(linear_finish_kernel, dim3((unsigned)mg_cdiv(mn, 256)), dim3(256), 0, st,
-                           (const float*)work, y, mn, N, p.ksplit, p.e);
+                           (const float*)work, y, mn, N, p.ksplit, p.e, p.perm_L, p.perm_C);
         MG_CHECK_LAUNCH("linear_finish_kernel");
     }
     return MG_OK;

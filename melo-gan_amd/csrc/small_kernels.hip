@@ -161,44 +161,6 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restr
     if (sumsq) sumsq[c] = (float)s2;
 }
 
-// groups > 1: independent batches of R rows each (the generator forward of the critic step and of the generator step as
-// one 2B-row pass): statistics per group, running statistics updated group after group -- exactly what two consecutive
-// forward passes do.
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nsplit, int C,
-                                                             long R, float momentum, float eps, float* running_mean,
-                                                             float* running_var, float* save_mean,
-                                                             float* save_invstd, int groups) {
-    for (int g = 0; g < groups; ++g) {
-        double s1, s2;
-        int c;
-        const bool mine = reduce_partials(part + (long)g * (RED_SPLITS + 1) * 2 * C, nsplit, C, true, s1, s2, c);
-        __syncthreads();
-        if (!mine) continue;
-        const double mean = s1 / (double)R;
-        double var = s2 / (double)R - mean * mean;
-        if (var < 0.0) var = 0.0;
-        save_mean[(long)g * C + c] = (float)mean;
-        save_invstd[(long)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-        }
-    }
-}
-
-__global__ void bn_apply_kernel(const float* __restrict__ z, float* __restrict__ a, long n, int C,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ mean, const float* __restrict__ invstd, int act, long group_n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    const long gc = (i / group_n) * C + c;           // statistics of the element's row group
-    // fp64 per-element math (free at HBM-bound rates; matches ATen's CPU accumulate type)
-    const double v = ((double)z[i] - (double)mean[gc]) * (double)invstd[gc] * (double)gamma[c] + (double)beta[c];
-    a[i] = mg_act(act, (float)v);
-}
-
 __global__ void bn_eval_kernel(const float* __restrict__ z, float* __restrict__ a, long n, int C,
                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ rm, const float* __restrict__ rv, float eps, int act) {
@@ -218,89 +180,253 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] + ((cb ? cb[c] : 0.f) - rm[c]) * s;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int nsplit, int C,
-                                                           float* dgamma, float* dbeta, double* sums /* [2][C] */) {
-    double s1, s2;
-    int c;
-    if (!reduce_partials(part, nsplit, C, true, s1, s2, c)) return;
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
-    sums[c] = s1;
-    sums[C + c] = s2;
-}
-
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ a,
-                                    const float* __restrict__ z, float* __restrict__ dz, long n, int C, long R,
-                                    const float* __restrict__ gamma, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const double* __restrict__ sums, int act,
-                                    const float* __restrict__ beta) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C);
-    const double is = (double)invstd[c];
-    const double xh = ((double)z[i] - (double)mean[c]) * is;
-    const float ref = act == MG_ACT_GELU ? (float)(xh * (double)gamma[c] + (double)beta[c]) : a[i];
-    const double dy = (double)(da[i] * mg_act_grad(act, ref));
-    const double invR = 1.0 / (double)R;
-    dz[i] = (float)((double)gamma[c] * is * (dy - sums[c] * invR - xh * sums[C + c] * invR));
-}
-
-// ---------------- BatchNorm from the producing convolution's partial statistics ----------------
-// part[g*np + p][2][C] (float): per-(workgroup, wave) column sums written by mg_conv16_stats.  A block owns 64 channels
-// x one row slice of one group: it first reduces ITS channels' partials (fixed order, fp64) through LDS, then applies.
-// blockIdx.y == 0 also publishes the statistics of every group and moves the running statistics, group after group.
-__device__ __forceinline__ void reduce_parts64(const float* __restrict__ part, int np, int C, int c0, double (*sh)[64],
-                                               double& s1, double& s2) {
+// ---------------- BatchNorm from the producing convolution's partial statistics: ONE launch ----------------
+// part[g*np + p][3][C] (float): per-(workgroup, wave) column partials written by mg_conv16_stats -- the sum, the sum of
+// squares about that wave's OWN mean, and the number of rows.  A block owns 64 channels x one row slice of one group: it
+// first combines ITS channels' partials (fixed order, fp64, parallel-variance rule: n = sum n_p, mean = sum S_p / n,
+// M2 = sum M2_p + sum S_p^2 / n_p - (sum S_p)^2 / n -- the between-wave term in fp64 from fp32 inputs, never E[x^2] - mean^2
+// of the raw data), then applies.  The (row slice 0, group 0) block of every channel block also publishes the statistics
+// of every group and moves the running statistics, group after group -- what two consecutive forward passes do.
+// (Was two launches: a finishing kernel and the apply pass; a dependent launch costs ~5 us, the redundant combine < 1.)
+__device__ __forceinline__ void combine_parts64(const float* __restrict__ part, int np, int C, int c0, double (*sh)[64],
+                                                double& mean, double& var) {
     const int cx = threadIdx.x & 63, pl = threadIdx.x >> 6;      // 4 partial lanes per channel
-    double a = 0.0, b = 0.0;
+    double A = 0.0, Q = 0.0, Bt = 0.0, n = 0.0;
     if (c0 + cx < C) {
-        // eight independent load pairs in flight per round (a plain loop waits for every round trip in turn)
+        // eight independent load triples in flight per round (a plain loop waits for every round trip in turn)
         for (int q0 = pl; q0 < np; q0 += 32) {
-            float va[8], vb[8];
+            float va[8], vq[8], vn[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // always load (clamped row), select afterwards: a load behind a runtime condition makes hipcc branch
                 // around it and wait for each one in turn
                 const int q = q0 + 4 * j;
-                const long o = ((long)(q < np ? q : np - 1) * 2) * C + c0 + cx;
+                const long o = ((long)(q < np ? q : np - 1) * 3) * C + c0 + cx;
                 va[j] = part[o];
-                vb[j] = part[o + C];
+                vq[j] = part[o + C];
+                vn[j] = part[o + 2 * (long)C];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (q0 + 4 * j < np) { a += (double)va[j]; b += (double)vb[j]; }
+                if (q0 + 4 * j < np && vn[j] > 0.f) {
+                    const double a = (double)va[j], c = (double)vn[j];
+                    A += a; Q += (double)vq[j]; Bt += a * a / c; n += c;
+                }
         }
     }
     __syncthreads();
-    sh[pl][cx] = a;
-    sh[4 + pl][cx] = b;
+    sh[pl][cx] = A; sh[4 + pl][cx] = Q; sh[8 + pl][cx] = Bt; sh[12 + pl][cx] = n;
     __syncthreads();
-    s1 = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
-    s2 = sh[4][cx] + sh[5][cx] + sh[6][cx] + sh[7][cx];
+    A = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+    Q = (sh[4][cx] + sh[5][cx]) + (sh[6][cx] + sh[7][cx]);
+    Bt = (sh[8][cx] + sh[9][cx]) + (sh[10][cx] + sh[11][cx]);
+    n = (sh[12][cx] + sh[13][cx]) + (sh[14][cx] + sh[15][cx]);
+    mean = n > 0.0 ? A / n : 0.0;
+    double m2 = Q + (Bt - A * mean);
+    if (m2 < 0.0) m2 = 0.0;
+    var = n > 0.0 ? m2 / n : 0.0;
 }
 
-// Final stage for statistics that arrive as conv16 partials: one block per 64 channels, every group in turn (fixed order,
-// fp64): batch mean / invstd per group, running statistics moved group after group.  The apply pass is bn_apply_kernel.
-__global__ __launch_bounds__(256) void bn_parts_final_kernel(const float* __restrict__ part, int np, int groups, long R, int C,
-                                                             float momentum, float eps, float* running_mean,
-                                                             float* running_var, float* save_mean, float* save_invstd) {
-    __shared__ double sh[8][64];
+// the same combine for the fp64 (sum, sum of squares) partials of colsum_partial_kernel<0> (tensors no conv16 launch produced):
+// part[g][split][2][C], mean = S1 / R, var = S2 / R - mean^2 in fp64
+__device__ __forceinline__ void combine_colsum64(const double* __restrict__ part, int np, int C, int c0, long R, double (*sh)[64],
+                                                 double& mean, double& var) {
+    const int cx = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    double A = 0.0, Q = 0.0;
+    if (c0 + cx < C)
+        for (int q0 = pl; q0 < np; q0 += 32) {
+            double va[8], vq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + 4 * j;
+                const long o = ((long)(q < np ? q : np - 1) * 2) * C + c0 + cx;
+                va[j] = part[o];
+                vq[j] = part[o + C];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (q0 + 4 * j < np) { A += va[j]; Q += vq[j]; }
+        }
+    __syncthreads();
+    sh[pl][cx] = A; sh[4 + pl][cx] = Q;
+    __syncthreads();
+    A = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+    Q = (sh[4][cx] + sh[5][cx]) + (sh[6][cx] + sh[7][cx]);
+    mean = A / (double)R;
+    var = Q / (double)R - mean * mean;
+    if (var < 0.0) var = 0.0;
+}
+
+// PT = float: conv16 partials (np rows of 3 planes per group); PT = double: colsum partials ((RED_SPLITS + 1) * 2 * C per group)
+template <typename PT>
+__global__ __launch_bounds__(256) void bn_parts_apply_kernel(const PT* __restrict__ part, int np, int groups, long R, int C,
+                                                             float momentum, float eps, float* running_mean, float* running_var,
+                                                             float* save_mean, float* save_invstd, const float* __restrict__ z,
+                                                             float* __restrict__ a, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int act, long rows_per) {
+    __shared__ double sh[16][64];
+    __shared__ float s_mean[64], s_istd[64];
     const int c0 = blockIdx.x * 64, cx = threadIdx.x & 63;
-    for (int g = 0; g < groups; ++g) {
-        double s1, s2;
-        reduce_parts64(part + (long)g * np * 2 * C, np, C, c0, sh, s1, s2);
-        if (threadIdx.x < 64 && c0 + cx < C) {
-            const double mean = s1 / (double)R;
-            double var = s2 / (double)R - mean * mean;
-            if (var < 0.0) var = 0.0;
-            save_mean[(long)g * C + c0 + cx] = (float)mean;
-            save_invstd[(long)g * C + c0 + cx] = (float)(1.0 / sqrt(var + (double)eps));
-            if (running_mean) {
-                const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-                running_mean[c0 + cx] = (float)((1.0 - momentum) * running_mean[c0 + cx] + momentum * mean);
-                running_var[c0 + cx] = (float)((1.0 - momentum) * running_var[c0 + cx] + momentum * unb);
+    const int g = blockIdx.z;
+    if (blockIdx.y == 0 && g == 0) {           // the publisher: every group in turn
+        for (int gg = 0; gg < groups; ++gg) {
+            double mean, var;
+            if constexpr (sizeof(PT) == 4) combine_parts64(part + (long)gg * np * 3 * C, np, C, c0, sh, mean, var);
+            else combine_colsum64(part + (long)gg * (RED_SPLITS + 1) * 2 * C, np, C, c0, R, sh, mean, var);
+            if (threadIdx.x < 64 && c0 + cx < C) {
+                const float mf = (float)mean, isf = (float)(1.0 / sqrt(var + (double)eps));
+                save_mean[(long)gg * C + c0 + cx] = mf;
+                save_invstd[(long)gg * C + c0 + cx] = isf;
+                if (gg == 0) { s_mean[cx] = mf; s_istd[cx] = isf; }
+                if (running_mean) {
+                    const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+                    running_mean[c0 + cx] = (float)((1.0 - momentum) * running_mean[c0 + cx] + momentum * mean);
+                    running_var[c0 + cx] = (float)((1.0 - momentum) * running_var[c0 + cx] + momentum * unb);
+                }
             }
         }
+    } else {
+        double mean, var;
+        if constexpr (sizeof(PT) == 4) combine_parts64(part + (long)g * np * 3 * C, np, C, c0, sh, mean, var);
+        else combine_colsum64(part + (long)g * (RED_SPLITS + 1) * 2 * C, np, C, c0, R, sh, mean, var);
+        if (threadIdx.x < 64 && c0 + cx < C) {
+            s_mean[cx] = (float)mean;
+            s_istd[cx] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    // apply: 16 float4 lanes x 16 row lanes over this block's 64 channels and row slice
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = c0 + 4 * cq;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per;
+    long r1 = r0 + rows_per;
+    if (r1 > R) r1 = R;
+    const bool vec = ((C & 3) == 0) && (c + 3 < C);
+    double mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool in = c + e < C;
+        mu[e] = (double)s_mean[4 * cq + e];
+        is[e] = (double)s_istd[4 * cq + e];
+        ga[e] = in ? (double)gamma[c + e] : 0.0;
+        be[e] = in ? (double)beta[c + e] : 0.0;
+    }
+    const float* zg = z + (long)g * R * C;
+    float* ag = a + (long)g * R * C;
+    for (long r = r0 + ry; r < r1; r += 16) {
+        const long i = r * C + c;
+        if (vec) {
+            const float4 t = *reinterpret_cast<const float4*>(zg + i);
+            const float zv[4] = {t.x, t.y, t.z, t.w};
+            float o[4];
+            // fp64 per-element math (free at HBM-bound rates; matches ATen's CPU accumulate type)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (float)(((double)zv[e] - mu[e]) * is[e] * ga[e] + be[e]);
+            if (act == MG_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = mg_act(MG_ACT_RELU, o[e]);
+            } else if (act != MG_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = mg_act(act, o[e]);
+            }
+            *reinterpret_cast<float4*>(ag + i) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) ag[i + e] = mg_act(act, (float)(((double)zg[i + e] - mu[e]) * is[e] * ga[e] + be[e]));
+        }
+    }
+}
+
+// BatchNorm backward, second (last) launch: every block sums ITS 64 channels' fp64 partials of colsum_partial_kernel<1>
+// (fixed order), then applies to its row slice; row slice 0 also writes dgamma / dbeta.  (Was a finishing launch + an apply
+// launch.)
+__global__ __launch_bounds__(256) void bn_bwd_parts_apply_kernel(const double* __restrict__ part, int nsplit, int C, long R,
+                                                                 const float* __restrict__ da, const float* __restrict__ a,
+                                                                 const float* __restrict__ z, float* __restrict__ dz,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* dgamma, float* dbeta, int act, long rows_per) {
+    __shared__ double sh[8][64];
+    __shared__ double s1[64], s2[64];
+    const int c0 = blockIdx.x * 64, cx = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    {
+        double t1 = 0.0, t2 = 0.0;
+        if (c0 + cx < C)
+            for (int q0 = pl; q0 < nsplit; q0 += 32) {
+                double va[8], vb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = q0 + 4 * j;
+                    const long o = ((long)(q < nsplit ? q : nsplit - 1) * 2) * C + c0 + cx;
+                    va[j] = part[o];
+                    vb[j] = part[o + C];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (q0 + 4 * j < nsplit) { t1 += va[j]; t2 += vb[j]; }
+            }
+        sh[pl][cx] = t1;
+        sh[4 + pl][cx] = t2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const double u1 = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+            const double u2 = (sh[4][cx] + sh[5][cx]) + (sh[6][cx] + sh[7][cx]);
+            s1[cx] = u1;
+            s2[cx] = u2;
+            if (blockIdx.y == 0 && c0 + cx < C) {
+                dbeta[c0 + cx] = (float)u1;
+                dgamma[c0 + cx] = (float)u2;
+            }
+        }
+        __syncthreads();
+    }
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = c0 + 4 * cq;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per;
+    long r1 = r0 + rows_per;
+    if (r1 > R) r1 = R;
+    const bool vec = ((C & 3) == 0) && (c + 3 < C);
+    const bool pre = act == MG_ACT_GELU;
+    const double invR = 1.0 / (double)R;
+    double mu[4], is[4], ga[4], be[4], k1[4], k2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool in = c + e < C;
+        mu[e] = in ? (double)mean[c + e] : 0.0;
+        is[e] = in ? (double)invstd[c + e] : 0.0;
+        ga[e] = in ? (double)gamma[c + e] : 0.0;
+        be[e] = (in && pre) ? (double)beta[c + e] : 0.0;
+        k1[e] = s1[4 * cq + e];
+        k2[e] = s2[4 * cq + e];
+    }
+    for (long r = r0 + ry; r < r1; r += 16) {
+        const long i = r * C + c;
+        float dv[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0}, zv[4] = {0, 0, 0, 0};
+        if (vec) {
+            const float4 t = *reinterpret_cast<const float4*>(da + i);
+            const float4 ta = *reinterpret_cast<const float4*>(a + i);
+            const float4 tz = *reinterpret_cast<const float4*>(z + i);
+            dv[0] = t.x; dv[1] = t.y; dv[2] = t.z; dv[3] = t.w;
+            av[0] = ta.x; av[1] = ta.y; av[2] = ta.z; av[3] = ta.w;
+            zv[0] = tz.x; zv[1] = tz.y; zv[2] = tz.z; zv[3] = tz.w;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) { dv[e] = da[i + e]; av[e] = a[i + e]; zv[e] = z[i + e]; }
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double xh = ((double)zv[e] - mu[e]) * is[e];
+            const float ref = pre ? (float)(xh * ga[e] + be[e]) : av[e];
+            const double dy = (double)(dv[e] * mg_act_grad(act, ref));
+            o[e] = (float)(ga[e] * is[e] * (dy - k1[e] * invR - xh * k2[e] * invR));
+        }
+        if (vec) *reinterpret_cast<float4*>(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
+        else
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) dz[i + e] = o[e];
     }
 }
 
@@ -340,10 +466,21 @@ __global__ __launch_bounds__(256) void meanT_fwd_kernel(const float* __restrict_
 }
 
 // VEC: four channels per thread, 16-byte accesses (C % 4 == 0, aligned tensors)
+// Optional rider (mean_out != nullptr): ONE extra block at the end of the grid writes mean_out[0] = mean_scale * mean(mean_src)
+// -- the generator's adversarial loss -mean(D(fake)) (src/gan/train_gan.py:224) needs no launch of its own.
 template <bool VEC>
 __global__ void meanT_bwd_kernel(const float* __restrict__ dh, float* __restrict__ dz, long n, int T, int C,
-                                 const float* __restrict__ gref, int gact, const float* __restrict__ gscale) {
+                                 const float* __restrict__ gref, int gact, const float* __restrict__ gscale,
+                                 const float* __restrict__ mean_src, float* mean_out, int mean_n, float mean_scale) {
     constexpr int NV = VEC ? 4 : 1;
+    if (mean_out && blockIdx.x == gridDim.x - 1) {
+        __shared__ float sh[16];
+        float r = 0.f;
+        for (int b = threadIdx.x; b < mean_n; b += blockDim.x) r += mean_src[b];
+        r = block_sum(r, sh);
+        if (threadIdx.x == 0) mean_out[0] = mean_scale * r / (float)mean_n;
+        return;
+    }
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * NV;
     if (i >= n) return;
     const int c = (int)(i % C);
@@ -490,10 +627,38 @@ __global__ void dhead_fwd_bwd_kernel(const float* __restrict__ ds, const float* 
     if (lane == 0) s[b] = acc + bias[0];
 }
 
-// one wave per output element j: lanes stride over the batch rows, shuffle-reduce
+struct DLoss { const float* s; const float* norms; float lambda_gp; float* out; float* gp_out; int nb; };
+__device__ __forceinline__ void wgan_d_loss_block(const DLoss& L) {
+    __shared__ float sh[16];
+    float r = 0.f, f = 0.f, q = 0.f;
+    for (int b = threadIdx.x; b < L.nb; b += blockDim.x) {
+        r += L.s[b];
+        f += L.s[L.nb + b];
+        const float d = L.norms[b] - 1.f;
+        q += d * d;
+    }
+    r = block_sum(r, sh);
+    f = block_sum(f, sh);
+    q = block_sum(q, sh);
+    if (threadIdx.x == 0) {
+        const float mr = r / (float)L.nb, mf = f / (float)L.nb, pen = q / (float)L.nb;
+        L.gp_out[0] = pen;
+        L.out[0] = mf - mr + L.lambda_gp * pen;
+        L.out[1] = mr;
+        L.out[2] = mf;
+    }
+}
+
+// one wave per output element j: lanes stride over the batch rows, shuffle-reduce.  Optional rider (loss.out != nullptr):
+// one extra block at the end of the grid computes the critic's loss scalars (mg_wgan_d_loss_gp) -- logging only, nothing
+// in the step depends on them, so they need no launch of their own.
 __global__ void dhead_wgrad_kernel(const float* __restrict__ ds, const float* __restrict__ f,
                                    const float* __restrict__ emb, const float* __restrict__ gf, float* dw,
-                                   float* dbias, int nb, int ng, int Be, int F, int E) {
+                                   float* dbias, int nb, int ng, int Be, int F, int E, const DLoss loss) {
+    if (loss.out && blockIdx.x == gridDim.x - 1) {
+        wgan_d_loss_block(loss);
+        return;
+    }
     const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     float s = 0.f;
@@ -520,7 +685,7 @@ __global__ void gp_interp_kernel(const float* __restrict__ real, const float* __
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const float a = alpha[i / n];
-    xhat[i] = a * real[i] + (1.f - a) * fake[i];
+    xhat[i] = fmaf(a, real[i], (1.f - a) * fake[i]);      // the same expression as conv16's mix rider
 }
 
 // One workgroup per sample.  The sample's slice stays in registers between the norm and the scaling pass when it
@@ -601,12 +766,12 @@ __global__ void wgan_d_loss_kernel(const float* s, const float* gp, const float*
     }
 }
 
-__global__ void neg_mean_kernel(const float* s, float* out, int B) {
+__global__ void neg_mean_kernel(const float* s, float* out, int B, float scale) {
     __shared__ float sh[16];
     float r = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) r += s[b];
     r = block_sum(r, sh);
-    if (threadIdx.x == 0) out[0] = -r / (float)B;
+    if (threadIdx.x == 0) out[0] = scale * r / (float)B;
 }
 
 __global__ void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, float* loss,
@@ -656,6 +821,7 @@ struct StageJobs { mg_stage_job j[MG_MAX_STAGE_JOBS]; };
 __global__ void stage_rows_kernel(const StageJobs J, int n_rows) {
     const mg_stage_job job = J.j[blockIdx.z];
     const int r = blockIdx.y;
+    if (job.rows > 0 && r >= job.rows) return;      // a job may cover fewer rows than the launch
     long sr = r;
     if (job.idx) {
         sr = job.idx[r];
@@ -951,10 +1117,15 @@ int mg_bn_train_fwd_groups(const float* z, float* a, long R, int C, int groups, 
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit, (unsigned)groups);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, z, nullptr, nullptr, nullptr, nullptr, 0, R, C,
                        pl.rows_per, (double*)work, 1);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(nblk(C, FIN_CH)), dim3(256), 0, ST, (const double*)work, pl.nsplit, C, R,
-                       momentum, eps, running_mean, running_var, save_mean, save_invstd, groups);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C * groups)), dim3(256), 0, ST, z, a, R * C * groups, C, gamma, beta,
-                       save_mean, save_invstd, act, R * C);
+    const long cb = mg_cdiv(C, 64);
+    long slices = 512 / (cb * groups);
+    if (slices < 1) slices = 1;
+    if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
+    const long rows_per = mg_cdiv(R, slices);
+    slices = mg_cdiv(R, rows_per);
+    hipLaunchKernelGGL(bn_parts_apply_kernel<double>, dim3((unsigned)cb, (unsigned)slices, (unsigned)groups), dim3(256), 0, ST,
+                       (const double*)work, pl.nsplit, groups, R, C, momentum, eps, running_mean, running_var, save_mean,
+                       save_invstd, z, a, gamma, beta, act, rows_per);
     MG_CHECK_LAUNCH("bn_train_fwd");
     return MG_OK;
 }
@@ -972,10 +1143,16 @@ int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups
     MG_CHECK_ARG(part && z && a && gamma && beta && save_mean && save_invstd && R > 0 && C > 0 && groups >= 1 &&
                  part_rows_per_group > 0, "mg_bn_train_fwd_parts: bad args");
     MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "mg_bn_train_fwd_parts: running stats must come in pairs");
-    hipLaunchKernelGGL(bn_parts_final_kernel, dim3((unsigned)mg_cdiv(C, 64)), dim3(256), 0, ST, part, part_rows_per_group, groups,
-                       R, C, momentum, eps, running_mean, running_var, save_mean, save_invstd);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk(R * C * groups)), dim3(256), 0, ST, z, a, R * C * groups, C, gamma, beta,
-                       (const float*)save_mean, (const float*)save_invstd, act, R * C);
+    // row slices: ~512 blocks in all (2 per CU), at least 64 rows each
+    const long cb = mg_cdiv(C, 64);
+    long slices = 512 / (cb * groups);
+    if (slices < 1) slices = 1;
+    if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
+    const long rows_per = mg_cdiv(R, slices);
+    slices = mg_cdiv(R, rows_per);
+    hipLaunchKernelGGL(bn_parts_apply_kernel<float>, dim3((unsigned)cb, (unsigned)slices, (unsigned)groups), dim3(256), 0, ST, part,
+                       part_rows_per_group, groups, R, C, momentum, eps, running_mean, running_var, save_mean, save_invstd, z, a,
+                       gamma, beta, act, rows_per);
     MG_CHECK_LAUNCH("bn_train_fwd_parts");
     return MG_OK;
 }
@@ -988,14 +1165,17 @@ int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, 
     if (!work || work_bytes < mg_bn_workspace_bytes(C)) { mg_set_error("mg_bn_train_bwd: workspace too small"); return MG_EWORK; }
     const RedPlan pl = red_plan(R);
     double* part = (double*)work;
-    double* sums = part + (size_t)RED_SPLITS * 2 * C;
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit);
     hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), 0, ST, da, a, z, save_mean, save_invstd, act, R, C,
                        pl.rows_per, part, 1, gamma, beta);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nblk(C, FIN_CH)), dim3(256), 0, ST, (const double*)part, pl.nsplit, C, dgamma,
-                       dbeta, sums);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(R * C)), dim3(256), 0, ST, da, a, z, dz, R * C, C, R, gamma,
-                       save_mean, save_invstd, (const double*)sums, act, beta);
+    const long cb = mg_cdiv(C, 64);
+    long slices = 512 / cb;
+    if (slices < 1) slices = 1;
+    if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
+    const long rows_per = mg_cdiv(R, slices);
+    slices = mg_cdiv(R, rows_per);
+    hipLaunchKernelGGL(bn_bwd_parts_apply_kernel, dim3((unsigned)cb, (unsigned)slices), dim3(256), 0, ST, (const double*)part,
+                       pl.nsplit, C, R, da, a, z, dz, gamma, beta, save_mean, save_invstd, dgamma, dbeta, act, rows_per);
     MG_CHECK_LAUNCH("bn_train_bwd");
     return MG_OK;
 }
@@ -1025,17 +1205,26 @@ int mg_meanT_fwd(const float* a, float* h, int B, int T, int C, mg_stream_t stre
     return MG_OK;
 }
 
-int mg_meanT_bwd(const float* dh, float* dz, int B, int T, int C, const float* gref, int gact, const float* gscale,
-                 mg_stream_t stream) {
+int mg_meanT_bwd_mean(const float* dh, float* dz, int B, int T, int C, const float* gref, int gact, const float* gscale,
+                      const float* mean_src, float* mean_out, int mean_n, float mean_scale, mg_stream_t stream) {
     MG_CHECK_ARG(dh && dz && B > 0 && T > 0 && C > 0, "mg_meanT_bwd: bad args");
+    MG_CHECK_ARG(!mean_out || (mean_src && mean_n > 0), "mg_meanT_bwd_mean: the mean rider needs a source and a length");
     const long n = (long)B * T * C;
+    const unsigned extra = mean_out ? 1u : 0u;
     auto al16 = [](const void* q) { return q == nullptr || ((((uintptr_t)q) & 15) == 0); };
     if ((C & 3) == 0 && al16(dh) && al16(dz) && al16(gref))
-        hipLaunchKernelGGL(meanT_bwd_kernel<true>, dim3(nblk(n / 4)), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale);
+        hipLaunchKernelGGL(meanT_bwd_kernel<true>, dim3(nblk(n / 4) + extra), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale,
+                           mean_src, mean_out, mean_n, mean_scale);
     else
-        hipLaunchKernelGGL(meanT_bwd_kernel<false>, dim3(nblk(n)), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale);
+        hipLaunchKernelGGL(meanT_bwd_kernel<false>, dim3(nblk(n) + extra), dim3(256), 0, ST, dh, dz, n, T, C, gref, gact, gscale,
+                           mean_src, mean_out, mean_n, mean_scale);
     MG_CHECK_LAUNCH("meanT_bwd");
     return MG_OK;
+}
+
+int mg_meanT_bwd(const float* dh, float* dz, int B, int T, int C, const float* gref, int gact, const float* gscale,
+                 mg_stream_t stream) {
+    return mg_meanT_bwd_mean(dh, dz, B, T, C, gref, gact, gscale, nullptr, nullptr, 0, 0.f, stream);
 }
 
 int mg_layernorm_fwd(const float* x, float* y, float* xhat, int B, int D, const float* gamma, const float* beta,
@@ -1083,13 +1272,21 @@ int mg_dhead_fwd_bwd(const float* ds, const float* f, const float* emb, const fl
     return MG_OK;
 }
 
-int mg_dhead_wgrad(const float* ds, const float* f, const float* emb, const float* gf, float* dw, float* dbias,
-                   int nb, int ng, int Be, int F, int E, mg_stream_t stream) {
+int mg_dhead_wgrad_loss(const float* ds, const float* f, const float* emb, const float* gf, float* dw, float* dbias,
+                        int nb, int ng, int Be, int F, int E, const float* s, const float* norms, float lambda_gp,
+                        float* loss_out, float* gp_out, int nb_loss, mg_stream_t stream) {
     MG_CHECK_ARG(ds && f && dw && dbias, "mg_dhead_wgrad: bad args");
-    hipLaunchKernelGGL(dhead_wgrad_kernel, dim3(nblk(F + E + 1, 4)), dim3(256), 0, ST, ds, f, emb, gf, dw, dbias, nb, ng,
-                       Be > 0 ? Be : 1, F, emb ? E : 0);
+    MG_CHECK_ARG(!loss_out || (s && norms && gp_out && nb_loss > 0), "mg_dhead_wgrad_loss: the loss rider needs s, norms, gp_out");
+    const DLoss loss{s, norms, lambda_gp, loss_out, gp_out, nb_loss};
+    hipLaunchKernelGGL(dhead_wgrad_kernel, dim3(nblk(F + E + 1, 4) + (loss_out ? 1u : 0u)), dim3(256), 0, ST, ds, f, emb, gf, dw,
+                       dbias, nb, ng, Be > 0 ? Be : 1, F, emb ? E : 0, loss);
     MG_CHECK_LAUNCH("dhead_wgrad");
     return MG_OK;
+}
+
+int mg_dhead_wgrad(const float* ds, const float* f, const float* emb, const float* gf, float* dw, float* dbias,
+                   int nb, int ng, int Be, int F, int E, mg_stream_t stream) {
+    return mg_dhead_wgrad_loss(ds, f, emb, gf, dw, dbias, nb, ng, Be, F, E, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
 }
 
 int mg_gp_interp(const float* real, const float* fake, const float* alpha, float* xhat, int B, long n,
@@ -1136,8 +1333,15 @@ int mg_softmax_ce(const float* logits, const int64_t* target, float* loss, float
 
 int mg_neg_mean(const float* s, float* out, int B, mg_stream_t stream) {
     MG_CHECK_ARG(s && out && B > 0, "mg_neg_mean: bad args");
-    hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(256), 0, ST, s, out, B);
+    hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(256), 0, ST, s, out, B, -1.f);
     MG_CHECK_LAUNCH("neg_mean");
+    return MG_OK;
+}
+
+int mg_mean_scaled(const float* src, float* out, int n, float scale, mg_stream_t stream) {
+    MG_CHECK_ARG(src && out && n > 0, "mg_mean_scaled: bad args");
+    hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(256), 0, ST, src, out, n, scale);
+    MG_CHECK_LAUNCH("mean_scaled");
     return MG_OK;
 }
 
@@ -1173,7 +1377,8 @@ int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t 
     for (int i = 0; i < n_jobs; ++i) {
         const mg_stage_job& j = jobs[i];
         MG_CHECK_ARG(j.src && j.dst && j.row_bytes > 0 && (j.row_bytes & 3) == 0 && j.src_rows > 0 &&
-                         ((((uintptr_t)j.src | (uintptr_t)j.dst)) & 3) == 0 && (j.idx || j.src_rows >= n_rows),
+                         ((((uintptr_t)j.src | (uintptr_t)j.dst)) & 3) == 0 && j.rows >= 0 && j.rows <= n_rows &&
+                         (j.idx || j.src_rows >= (j.rows > 0 ? j.rows : n_rows)),
                      "mg_stage_rows: job %d: rows must be non-empty multiples of 4 bytes, 4-byte aligned, and the source "
                      "must hold n_rows rows when it is not indexed", i);
         MG_CHECK_ARG(j.dst_pitch == 0 || (j.dst_pitch >= j.row_bytes && (j.dst_pitch & 3) == 0),

@@ -319,6 +319,12 @@ class GanEngine:
         # fork/join cost more cross-queue latency than the overlap returned once the kernels filled the chip -- 1.70 ms
         # single-stream vs 1.73-1.82 -- and were removed; independent launches of one kernel share a launch instead.)
         self._init_wq()
+        # x_hat rides in the launch that produces the critic step's fake batch where conv16 runs the last deconvolution
+        # (for B and for 2B rows) and the generated roll fills the whole time axis (no zero-pad tail, models.py:78-81)
+        self._mix_fused = (self.L3 == T and ("G.decoder.deconv.6.weight", "fwd") in self.wq and
+                           all(ops.conv16_supported(nb, 4 * self.red, 64, C, True, 8 * self.red) for nb in (B, 2 * B)) and
+                           os.environ.get("MELO_MIX_FUSED", "1") == "1")
+        self._init_chains()
         self.world_size = 1
         self.p2_world = 0          # > 0: decoder.pre.2's weight gradient comes from all-gathered factors (enable_p2_gather)
         self.capture_locked = False   # DataParallel.prepare(): every graph is captured before the first collective
@@ -352,6 +358,32 @@ class GanEngine:
         self._wq_tab = {"D": ops.wq_table(ent["D"]) if ent["D"] else None,
                         "GE": ops.wq_table(ent["GE"]) if ent["GE"] else None}
 
+    def _init_chains(self):
+        """Which small per-sample layer stacks run as ONE row-chain launch (csrc/row_chain.hip) instead of a launch per
+        layer: the numeric encoder (forward with the generator-input assembly; data-gradient), the critic's tail (fc +
+        scoring head + their data-gradients) and the emotion classifier's tail (pooling, project, MLP, head, cross-entropy
+        and every data-gradient).  Decided once from the shapes (a replayed graph runs no Python); MELO_CHAINS=0: the
+        per-layer launches everywhere (what the chains are tested against)."""
+        on = os.environ.get("MELO_CHAINS", "1") == "1"
+        Ch = ops.Chain
+        h1, h2 = self.enc_hidden
+        PE, PD, PED = self._ep, self.D.p, self.ED.p
+        self._chain_e = (on and self.num_in <= 64 and Ch.supported(self.num_in, h1, h2, self.E, self.noise_dim, max(self.latent_dim, 1))
+                         and Ch.weights_ok(PE("net.1.weight"), PE("net.4.weight"), PE("net.7.weight")))
+        self._chain_d = on and Ch.supported(256, self.E) and Ch.weights_ok(PD["fc.1.weight"])
+        mh = tuple(self.ed_cfg.get("mlp_hidden", (256, 128)))
+        ws = [PED[f"classifier.net.{3 * j}.weight"] for j in range(len(mh))] + [PED["classifier.head.weight"]]
+        dims = list(mh) + [self.ed_feat_dim]
+        n_ops = 2 * (len(mh) + 1) + 3                     # load, MLP + head forward, CE, dlogits store, their data-gradients
+        if self.ed_mode == "notes":
+            ws.append(PED["encoder.project.weight"])
+            dims.append(self.ed_pool.shape[1])
+            n_ops += 2
+        self._chain_ed = (on and self.n_classes <= 32 and Ch.supported(*dims) and Ch.weights_ok(*ws) and
+                          n_ops <= ops.L.CHAIN_MAX_OPS)
+        self.ed_loss_rows = torch.zeros(self.B, device=self.dev)      # per-sample cross-entropy terms (their mean is `emo`)
+        self._gin_done = False
+
     def params_changed(self):
         """Call after writing parameters other than through the optimiser step (load_state and init_weights do):
         refreshes the derived copies -- the WQ-layout convolution weights and the folded emotion discriminator."""
@@ -361,33 +393,54 @@ class GanEngine:
         # stale fold (and a fold launched during capture would be baked into every replay)
         self.fold_ed()
 
-    def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, stats=None, pool=None, **epi):
+    class _Riders:
+        """What a _conv5s2 launch did besides the convolution (the caller runs a separate kernel for what it did not)."""
+        __slots__ = ("parts", "pooled", "perm", "mixed")
+
+        def __init__(self):
+            self.parts, self.pooled, self.perm, self.mixed = None, False, False, False
+
+    def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, stats=None, pool=None, perm=False,
+                 mix=None, **epi):
         """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
         convT_fwd / convT_dgrad (nn.ConvTranspose1d, weight (Cin,Cout,5)).  conv16 (no split-K, no finish launch) wherever
         it covers the shape (faster on every cfg2 layer, tools/conv16_bench.py); the 64x64-tile kernel otherwise.
-        stats = rows per BatchNorm group: ask the launch for per-column partial statistics of what it stores (the
-        BatchNorm that follows then needs no reduction pass).  Returns (part, part_rows) if it did, else None.
-        pool = (B, N) tensor: also write the temporal mean of the output there if the launch can (returns True), else the
-        caller runs the pooling kernel (returns None)."""
+        Riders, taken by the same launch where conv16 runs it (returned _Riders says which):
+          stats = rows per BatchNorm group: per-column partial statistics of what it stores (the BatchNorm that follows
+                  then needs no reduction pass) -> .parts = (part, part_rows);
+          pool = (B, N) tensor: the temporal mean of the output -> .pooled;
+          perm: y is (B, N, Tout), the order of the Linear output the reference views as (B, C, L) -> .perm; when the
+                launch cannot, NOTHING is launched and the caller takes its two-launch route;
+          mix = (real, alpha, out, rows): the gradient penalty's interpolate of the first `rows` samples -> .mixed."""
         w = fp.p[name]
+        res = GanEngine._Riders()
         transposed = kind in ("conv_dgrad", "convT_fwd")
         direction = "fwd" if kind.endswith("fwd") else "dgrad"
         N = w.shape[0] if kind in ("conv_fwd", "convT_dgrad") else w.shape[1]
         wq = self.wq.get((name, direction))
         B, Tin, Cin = x.shape
-        odd = transposed and y.shape[1] == 2 * Tin - 1 and kind == "conv_dgrad"
+        Ty = y.shape[2] if perm else y.shape[1]
+        odd = transposed and Ty == 2 * Tin - 1 and kind == "conv_dgrad"
         if wq is not None and ops.conv16_supported(B, Tin, Cin, N, transposed, (2 * Tin - (1 if odd else 0)) if transposed else 0):
+            kw = dict(epi)
             if pool is not None and kind == "conv_fwd" and ops.conv16_poolable(B, Tin, Cin, N):
-                ops.conv16_pool(x, wq, y, N, pool, 1.0 / y.shape[1], **epi)
-                return True
+                kw["pool"] = (pool, 1.0 / y.shape[1])
+                res.pooled = True
             if stats is not None:
                 tb, rows = ops.conv16_plan(B, Tin, N, transposed)
                 if stats % tb == 0:                 # no tile straddles two groups
-                    part = ops.workspace(8 * rows * N, x.device, "bn_part").view(torch.float32)
-                    ops.conv16(x, wq, y, N, transposed, odd=odd, stats=part, **epi)
-                    return part, rows
-            ops.conv16(x, wq, y, N, transposed, odd=odd, **epi)
-            return None
+                    part = ops.workspace(12 * rows * N, x.device, "bn_part").view(torch.float32)
+                    kw["stats"] = part
+                    res.parts = (part, rows)
+            if perm:
+                kw["perm"] = res.perm = True
+            if mix is not None:
+                kw["mix"] = mix
+                res.mixed = True
+            ops.conv16(x, wq, y, N, transposed, odd=odd, **kw)
+            return res
+        if perm:
+            return res                              # not launched: the caller's transpose route
         if kind == "conv_fwd":
             ops.conv1d_fwd(x, w, y, 2, **epi)
         elif kind == "conv_dgrad":
@@ -396,7 +449,7 @@ class GanEngine:
             ops.convT1d_fwd(x, w, y, **epi)
         else:
             ops.convT1d_dgrad(x, w, y, **epi)
-        return None
+        return res
 
     # -------------------------------------------------------------------------------------
     # state in / out
@@ -528,11 +581,32 @@ class GanEngine:
         B = self.B
         return {"d": (0, B), "g": (B, 2 * B), "both": (0, 2 * B)}[which]
 
-    def _e_fwd(self, train: bool, which: str = "g"):
-        """FeatureEncoder.forward (src/gan/feature_encoder.py:43-45) on the rows of `which`."""
+    def _e_fwd(self, train: bool, which: str = "g", gin: bool = False):
+        """FeatureEncoder.forward (src/gan/feature_encoder.py:43-45) on the rows of `which`.  gin: the caller runs the
+        generator next -- where the encoder is one row-chain launch it also assembles the generator's input
+        [noise | embedding (| latent)] (models.py:116-122), which _g_fwd then does not."""
         P = self._ep
         r0, r1 = self._rows(which)
         v = lambda name: getattr(self, name + "_2")[r0:r1]  # noqa: E731
+        if self._chain_e:
+            m1, m2 = ((self.dmask_2[0][r0:r1], self.dmask_2[1][r0:r1]) if train else (None, None))
+            ch = ops.Chain(r1 - r0)
+            ch.load(0, v("numeric"))
+            ch.layernorm(0, 1, P("net.0.weight"), P("net.0.bias"), xhat=v("e_xhat"), y=v("e_x0"))
+            ch.linear_fwd(1, 2, P("net.1.weight"), P("net.1.bias"), ACT_GELU, m1, zout=v("e_z1"), out=v("e_h1"))
+            ch.linear_fwd(2, 3, P("net.4.weight"), P("net.4.bias"), ACT_GELU, m2, zout=v("e_z2"), out=v("e_h2"))
+            ch.linear_fwd(3, 4, P("net.7.weight"), P("net.7.bias"), out=v("emb"))
+            if gin:
+                nd, E, g = self.noise_dim, self.E, v("gin")
+                ch.store(4, g[:, nd:nd + E])
+                ch.load(5, v("noise"))
+                ch.store(5, g[:, :nd])
+                if self.mode == "conditioning":
+                    ch.load(5, self.latent, mod=self.B)          # the batch's latent, the same rows for both halves
+                    ch.store(5, g[:, nd + E:nd + E + self.latent_dim])
+            ch.launch()
+            self._gin_done = gin
+            return
         ops.layernorm_fwd(v("numeric"), v("e_x0"), v("e_xhat"), P("net.0.weight"), P("net.0.bias"))
         m1, m2 = ((self.dmask_2[0][r0:r1], self.dmask_2[1][r0:r1]) if train else (None, None))
         ops.linear_fwd(v("e_x0"), P("net.1.weight"), v("e_h1"), bias=P("net.1.bias"), zout=v("e_z1"), act=ACT_GELU, emul=m1)
@@ -552,23 +626,33 @@ class GanEngine:
         if self.mode == "conditioning":
             for h in range(n // self.B):          # the batch's latent, once per half
                 blocks.append((self.latent, gin[h * self.B:(h + 1) * self.B, nd + E:nd + E + self.latent_dim], None))
-        if n == self.B:
+        if self._gin_done:
+            self._gin_done = False                  # assembled by the encoder's chain launch (_e_fwd(gin=True))
+        elif n == self.B:
             ops.stage_rows(blocks, n)
-        else:
-            ops.stage_rows(blocks[:2], n)
-            if len(blocks) > 2:
-                ops.stage_rows(blocks[2:], self.B)
+        else:       # one launch: the two-half blocks cover n rows, the per-half latent blocks B rows each
+            ops.stage_rows(blocks[:2] + [(s_, d_, i_, self.B) for (s_, d_, i_) in blocks[2:]], n)
         ops.linear_fwd(gin, P("noise_to_latent.net.0.weight"), v("a_n0"), bias=P("noise_to_latent.net.0.bias"), act=ACT_RELU)
         ops.linear_fwd(v("a_n0"), P("noise_to_latent.net.2.weight"), v("lat"), bias=P("noise_to_latent.net.2.bias"))
         ops.linear_fwd(v("lat"), P("decoder.pre.0.weight"), v("a_p0"), bias=P("decoder.pre.0.bias"), act=ACT_RELU)
-        ops.linear_fwd(v("a_p0"), P("decoder.pre.2.weight"), v("a_p2"), bias=P("decoder.pre.2.bias"), act=ACT_RELU)
-        ops.transpose_bcl_blc(v("a_p2").view(n, 256, self.red), v("y0"))
+        if n <= ops.SKINNY_MAX_ROWS and self.red > 1:
+            # pre.2's output straight into the channels-last (rows, L, 256) tensor the first deconvolution reads
+            # (models.py:70-73: view(B, 256, L) + permute): the Linear launch walks its weight rows in that order
+            ops.linear_fwd(v("a_p0"), P("decoder.pre.2.weight"), v("y0"), perm_L=self.red, bias=P("decoder.pre.2.bias"),
+                           act=ACT_RELU)
+        else:
+            ops.linear_fwd(v("a_p0"), P("decoder.pre.2.weight"), v("a_p2"), bias=P("decoder.pre.2.bias"), act=ACT_RELU)
+            ops.transpose_bcl_blc(v("a_p2").view(n, 256, self.red), v("y0"))
         st = self.B if train else None
         pr = self._conv5s2("convT_fwd", v("y0"), self.GE, "G.decoder.deconv.0.weight", v("z_d0"), stats=st, bias=P("decoder.deconv.0.bias"))
-        self._bn(v("z_d0"), v("a_d0"), "decoder.deconv.1", 0, train, which, pr)
+        self._bn(v("z_d0"), v("a_d0"), "decoder.deconv.1", 0, train, which, pr.parts)
         pr = self._conv5s2("convT_fwd", v("a_d0"), self.GE, "G.decoder.deconv.3.weight", v("z_d3"), stats=st, bias=P("decoder.deconv.3.bias"))
-        self._bn(v("z_d3"), v("a_d3"), "decoder.deconv.4", 1, train, which, pr)
-        self._conv5s2("convT_fwd", v("a_d3"), self.GE, "G.decoder.deconv.6.weight", out, bias=P("decoder.deconv.6.bias"))
+        self._bn(v("z_d3"), v("a_d3"), "decoder.deconv.4", 1, train, which, pr.parts)
+        # the critic-step half's fake batch also leaves x_hat = alpha * real + (1 - alpha) * fake (utils.py:76-79) in X0[:B]
+        mix = None
+        if train and which in ("d", "both") and self._mix_fused and out.data_ptr() == self.fake_d.data_ptr():
+            mix = (self.real, self.alpha, self.X0[:self.B], self.B)
+        self._conv5s2("convT_fwd", v("a_d3"), self.GE, "G.decoder.deconv.6.weight", out, mix=mix, bias=P("decoder.deconv.6.bias"))
         if train:
             self.num_batches_tracked += n // self.B
 
@@ -600,23 +684,39 @@ class GanEngine:
         self._conv5s2("conv_fwd", self.A1[:nb], self.D, "conv.2.weight", self.A2[:nb], bias=P["conv.2.bias"], act=ACT_LRELU)
         # AdaptiveAvgPool1d(1) rides in conv.4's launch where a sample's time axis is one wave tile (cfg2: 32 positions)
         if not self._conv5s2("conv_fwd", self.A2[:nb], self.D, "conv.4.weight", self.A3[:nb], pool=self.H[:nb],
-                             bias=P["conv.4.bias"], act=ACT_LRELU):
+                             bias=P["conv.4.bias"], act=ACT_LRELU).pooled:
             ops.meanT_fwd(self.A3[:nb], self.H[:nb])
+        if self._chain_d and not head:
+            return                  # fc + head + their data-gradients are ONE chain launch in _d_bwd_input(with_head=True)
         ops.linear_fwd(self.H[:nb], P["fc.1.weight"], self.Fh[:nb], bias=P["fc.1.bias"], act=ACT_LRELU)
         if head:
             ops.dhead_fwd(self.Fh[:nb], emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb])
 
-    def _d_bwd_input(self, ds: Tensor, nb: int, emb: Tensor, demb: Optional[Tensor], with_head: bool = False):
-        """Back-propagate ds through the critic down to dZ1 (grad wrt conv.0's pre-activation)."""
+    def _d_bwd_input(self, ds: Tensor, nb: int, emb: Tensor, demb: Optional[Tensor], with_head: bool = False, mean=None):
+        """Back-propagate ds through the critic down to dZ1 (grad wrt conv.0's pre-activation).  mean = (src, out, scale): a
+        scalar mean that rides in the pooling-backward launch (the generator's adversarial loss)."""
         P = self.D.p
-        if with_head:
-            ops.dhead_fwd_bwd(ds, self.Fh[:nb], emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb],
-                              self.dU[:nb], demb, nb_emb=nb if demb is not None else 0)
+        if with_head and self._chain_d and (demb is None or emb.shape[0] == nb):
+            # the critic's tail as one launch: fc + LeakyReLU, the scoring head, its input gradient (ds is a constant of
+            # the step) and fc's data-gradient (models.py:149-169)
+            ch = ops.Chain(nb)
+            ch.load(0, self.H[:nb])
+            ch.linear_fwd(0, 1, P["fc.1.weight"], P["fc.1.bias"], ACT_LRELU, out=self.Fh[:nb])
+            ch.dhead(1, 2, P["real_fake.weight"].view(-1), P["real_fake.bias"], emb, ds, self.s[:nb], demb=demb)
+            ch.store(2, self.dU[:nb])
+            ch.linear_dgrad(2, 3, P["fc.1.weight"], out=self.dH[:nb])
+            ch.launch()
         else:
-            ops.dhead_bwd(ds, self.Fh[:nb], P["real_fake.weight"].view(-1), self.dU[:nb], demb,
-                          nb_emb=nb if demb is not None else 0)
-        ops.linear_dgrad(self.dU[:nb], P["fc.1.weight"], self.dH[:nb])
-        ops.meanT_bwd(self.dH[:nb], self.dZ3[:nb], gref=self.A3[:nb], gact=ACT_LRELU)
+            if with_head and self._chain_d:         # _d_fwd left fc to the chain
+                ops.linear_fwd(self.H[:nb], P["fc.1.weight"], self.Fh[:nb], bias=P["fc.1.bias"], act=ACT_LRELU)
+            if with_head:
+                ops.dhead_fwd_bwd(ds, self.Fh[:nb], emb, P["real_fake.weight"].view(-1), P["real_fake.bias"], self.s[:nb],
+                                  self.dU[:nb], demb, nb_emb=nb if demb is not None else 0)
+            else:
+                ops.dhead_bwd(ds, self.Fh[:nb], P["real_fake.weight"].view(-1), self.dU[:nb], demb,
+                              nb_emb=nb if demb is not None else 0)
+            ops.linear_dgrad(self.dU[:nb], P["fc.1.weight"], self.dH[:nb])
+        ops.meanT_bwd(self.dH[:nb], self.dZ3[:nb], gref=self.A3[:nb], gact=ACT_LRELU, mean=mean)
         self._conv5s2("conv_dgrad", self.dZ3[:nb], self.D, "conv.4.weight", self.dZ2[:nb], gref=self.A2[:nb], gact=ACT_LRELU)
         self._conv5s2("conv_dgrad", self.dZ2[:nb], self.D, "conv.2.weight", self.dZ1[:nb], gref=self.A1[:nb], gact=ACT_LRELU)
 
@@ -684,6 +784,12 @@ class GanEngine:
             return
         ops.linear_dgrad(g, w, self.ed_dproj)
         ops.linear_dgrad(self.ed_dproj, P["encoder.project.weight"], self.ed_dpool)
+        self._ed_bwd_convs(dnotes)
+
+    def _ed_bwd_convs(self, dnotes: Tensor, mean=None):
+        """From the pooled features' gradient back to the notes: pooling backward (times conv3's GELU' and BatchNorm scale)
+        and the four convolutions' data-gradients.  mean: a scalar mean riding in the pooling-backward launch."""
+        P = self.ED.p
         last = len(self.ed_chans) - 1
         if self.ed_dtype == "bf16":
             ops.meanT_bwd_bf16(self.ed_dpool, self.ed_dz[last], self.ed_z[last], ACT_GELU, self.ed_scale[last])
@@ -692,7 +798,7 @@ class GanEngine:
                                  gscale=self.ed_scale[i - 1])
             ops.conv_s1_bf16(self.ed_dz[0], self.ed_wb_d[0], dnotes)   # fp32 out: the generator's gradient stays fp32
             return
-        ops.meanT_bwd(self.ed_dpool, self.ed_dz[last], gref=self.ed_z[last], gact=ACT_GELU, gscale=self.ed_scale[last])
+        ops.meanT_bwd(self.ed_dpool, self.ed_dz[last], gref=self.ed_z[last], gact=ACT_GELU, gscale=self.ed_scale[last], mean=mean)
         for i in range(last, 0, -1):
             ops.conv1d_dgrad(self.ed_dz[i], P[f"encoder.conv.{i}.net.0.weight"], self.ed_dz[i - 1], 1,
                              gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1])
@@ -708,9 +814,10 @@ class GanEngine:
         P, G = self.D.p, self.D.g
         if forward:
             # no_grad: embedding (dropout ON) and fake batch (BN train mode: running stats move)
-            self._e_fwd(True, "d")
+            self._e_fwd(True, "d", gin=True)
             self._g_fwd(self.fake_d, True, "d")
-        ops.gp_interp(self.real, self.fake_d, self.alpha, self.X0[:B])
+        if not self._mix_fused:                      # else deconv.6's launch of the critic-step half wrote x_hat (_g_fwd)
+            ops.gp_interp(self.real, self.fake_d, self.alpha, self.X0[:B])
         self._d_fwd(self.X0[:3 * B], 3 * B, self.emb_d, head=False)
         # one backward for [x_hat | real | fake] with ds = [1 | -1/B | +1/B]
         self._d_bwd_input(self.ds_d, 3 * B, self.emb_d, None, with_head=True)
@@ -722,7 +829,7 @@ class GanEngine:
         self._conv5s2("conv_fwd", self.TAN0, self.D, "conv.0.weight", self.TAN1, gref=self.A1[:B], gact=ACT_LRELU)
         self._conv5s2("conv_fwd", self.TAN1, self.D, "conv.2.weight", self.TAN2, gref=self.A2[:B], gact=ACT_LRELU)
         tz3_pooled = self._conv5s2("conv_fwd", self.TAN2, self.D, "conv.4.weight", self.TZ3, pool=self.ghb, gref=self.A3[:B],
-                                   gact=ACT_LRELU)
+                                   gact=ACT_LRELU).pooled
         # the three convolutions' weight gradients go out as ONE launch (+ one slab reduction) once their tangents
         # exist (ops.wgrad_multi): three launches of ~256 workgroups each plus three reductions before
         ops.wgrad_multi([
@@ -736,9 +843,9 @@ class GanEngine:
             ops.meanT_fwd(self.TZ3, self.ghb)
         ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[:B], gact=ACT_LRELU)
         ops.linear_wgrad(self.H[B:], self.dU[B:], G["fc.1.weight"], self.ghb, self.dU[:B], db=G["fc.1.bias"])
+        # the critic's loss scalars (logging only) ride in the head's weight-gradient launch
         ops.dhead_wgrad(self.ds_d[B:], self.Fh[B:], self.emb_d, self.gfb, G["real_fake.weight"].view(-1), G["real_fake.bias"],
-                        2 * B, B)
-        ops.wgan_d_loss(self.s[B:], self.gp, self.lambda_gp, self.loss_d_out, B, norms=self.norms)
+                        2 * B, B, loss=(self.s[B:], self.norms, self.lambda_gp, self.loss_d_out, self.gp, B))
 
     def d_backward_rng(self):
         """Production D-step front half: device RNG draw + d_backward as one capturable sequence."""
@@ -765,7 +872,7 @@ class GanEngine:
         same weights (train_gan.py:186-189 and :216-219 -- the generator is not updated in between), each half has its own
         noise, dropout masks and BatchNorm batch statistics, and the running statistics move twice, critic-step half first."""
         self._require_fold()
-        self._e_fwd(True, "both")
+        self._e_fwd(True, "both", gin=True)
         self._g_fwd(self.X0[2 * self.B:], True, "both")
 
     def dg_step_rng(self):
@@ -870,7 +977,7 @@ class GanEngine:
         """E_num + generator forward of the G-step: independent of the critic, so under data parallelism it runs while
         the critic's gradient all-reduce is in flight (DataParallel.step)."""
         self._require_fold()
-        self._e_fwd(True, "g")
+        self._e_fwd(True, "g", gin=True)
         self._g_fwd(self.notes, True, "g")
 
     def g_forward_rng(self):
@@ -893,9 +1000,69 @@ class GanEngine:
         part of the generator step that does not touch the critic -- under data parallelism it runs while the critic's
         gradient all-reduce is in flight (DataParallel.step)."""
         self._require_fold()
+        if self._chain_ed:
+            return self._ed_branch_chain()
         self._ed_fwd(self.notes)
         ops.softmax_ce(self.logits, self.emot_idx, self.emo, self.dlogits, self.lambda_emo)
         self._ed_bwd(self.dnotes if self.ed_mode == "notes" else None)
+
+    def _ed_branch_chain(self):
+        """g_ed_branch with the classifier's tail -- pooling, project, MLP, head, cross-entropy and every data-gradient back
+        to the pooled features (ed_model.py:61,86-95,147-165) -- as ONE row-chain launch between the convolutions' forward
+        and their data-gradients (was: 10 launches of ~5 us).  The loss scalar (the mean of the per-sample terms) rides in
+        the pooling-backward launch."""
+        P = self.ED.p
+        notes, bf16 = self.ed_mode == "notes", self.ed_dtype == "bf16"
+        last = len(self.ed_chans) - 1
+        ch = ops.Chain(self.B)
+        if notes:
+            x = self.notes
+            for i in range(len(self.ed_chans)):
+                ci, co, k = self.ed_chans[i]
+                if bf16:
+                    ops.conv_s1_bf16(x, self.ed_wb_f[i], self.ed_a[i], scale=self.ed_scale[i], shift=self.ed_shift[i],
+                                     zout=self.ed_z[i], act=ACT_GELU)
+                else:
+                    ops.conv_gather(x, self.ed_wt[i], self.ed_a[i], co, k, 1, k, co * k, scale=self.ed_scale[i],
+                                    shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+                x = self.ed_a[i]
+            if bf16:
+                ops.meanT_fwd_bf16(x, self.ed_pool)
+                ch.load(0, self.ed_pool)
+            else:
+                ch.mean_t(0, x, out=self.ed_pool)
+            ch.linear_fwd(0, 1, P["encoder.project.weight"], P["encoder.project.bias"], out=self.ed_proj)
+        else:
+            ch.load(1, self.lat)
+        cur = 1
+        nxt = lambda c: (c + 1) % ops.L.CHAIN_SLOTS  # noqa: E731
+        n = len(self.ed_cz)
+        for j in range(n):
+            ch.linear_fwd(cur, nxt(cur), P[f"classifier.net.{3 * j}.weight"], P[f"classifier.net.{3 * j}.bias"], ACT_GELU,
+                          zout=self.ed_cz[j], out=self.ed_ca[j])
+            cur = nxt(cur)
+        ch.linear_fwd(cur, nxt(cur), P["classifier.head.weight"], P["classifier.head.bias"], out=self.logits)
+        cur = nxt(cur)
+        # F.cross_entropy (mean over the batch) forward + backward; the generator's loss weighs it by lambda_emo
+        ch.softmax_ce(cur, nxt(cur), self.emot_idx, self.ed_loss_rows, self.lambda_emo / self.B, self.n_classes)
+        cur = nxt(cur)
+        ch.store(cur, self.dlogits)
+        w = P["classifier.head.weight"]
+        for j in reversed(range(n)):
+            ch.linear_dgrad(cur, nxt(cur), w, gref=self.ed_cz[j], gact=ACT_GELU, out=self.ed_dcz[j])
+            cur, w = nxt(cur), P[f"classifier.net.{3 * j}.weight"]
+        if not notes:
+            ch.linear_dgrad(cur, nxt(cur), w, out=self.ed_dfeat)
+            ch.launch()
+            ops.mean_scaled(self.ed_loss_rows, self.emo, 1.0)
+            return
+        ch.linear_dgrad(cur, nxt(cur), w, out=self.ed_dproj)
+        cur = nxt(cur)
+        ch.linear_dgrad(cur, nxt(cur), P["encoder.project.weight"], out=self.ed_dpool)
+        ch.launch()
+        if bf16:
+            ops.mean_scaled(self.ed_loss_rows, self.emo, 1.0)
+        self._ed_bwd_convs(self.dnotes, mean=None if bf16 else (self.ed_loss_rows, self.emo, 1.0))
 
     def g_critic_chain(self):
         """Critic forward + input gradient on the generated batch (with the UPDATED critic), added to the emotion
@@ -907,8 +1074,8 @@ class GanEngine:
         """The part of g_critic_chain that does not need the emotion branch's result."""
         B = self.B
         self._d_fwd(self.notes, B, self.emb, head=False)
-        self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True)
-        ops.neg_mean(self.s[:B], self.adv)
+        # adv = -mean(D(fake)) (train_gan.py:224) rides in the pooling-backward launch: s is written two launches earlier
+        self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True, mean=(self.s[:B], self.adv, -1.0))
 
     def g_critic_back(self):
         B = self.B
@@ -929,9 +1096,12 @@ class GanEngine:
                          self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
         # (Leaving BatchNorm backward's two column sums to the producing conv16 launch as well was built and measured:
         #  its epilogue then reads a and z, scattered and exposed at the kernel's tail -- no faster than the reduction pass.)
-        self._conv5s2("convT_dgrad", self.d_zd0, self.GE, "G.decoder.deconv.0.weight", self.d_y0)
-        # (B, red, 256) -> reference (B, 256*red) order, times relu'
-        ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red), gref=self.a_p2, gact=ACT_RELU)
+        # times pre.2's relu' (mask from y0 = its output as the deconvolution read it), stored in the reference's
+        # (B, 256*red) order: the launch writes (b, c, l) itself where conv16 runs it, else a transpose follows
+        if not self._conv5s2("convT_dgrad", self.d_zd0, self.GE, "G.decoder.deconv.0.weight", self.d_p2.view(B, 256, self.red),
+                             perm=True, gref=self.y0, gact=ACT_RELU).perm:
+            self._conv5s2("convT_dgrad", self.d_zd0, self.GE, "G.decoder.deconv.0.weight", self.d_y0, gref=self.y0, gact=ACT_RELU)
+            ops.transpose_bcl_blc(self.d_y0, self.d_p2.view(B, 256, self.red))
         # pre.2's weight gradient: launched by g_backward_b with the other weight gradients, or -- data parallel, factor
         # gather -- by g_p2_wgrad from every rank's (d_p2, a_p0)
 
@@ -969,13 +1139,23 @@ class GanEngine:
                                      db=GG("noise_to_latent.net.0.bias"), defer=True))
         ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
         # embedding gradient = generator-input slice + critic-head path, then E_num backward
-        ops.copy_cols(self.d_gin, self.noise_dim, self.demb, 0, self.E, accumulate=True)
         jobs.append(ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"), db=GEg("net.7.bias"), defer=True))
-        ops.linear_dgrad(self.demb, PE("net.7.weight"), self.d_ez2, gref=self.e_z2, gact=ACT_GELU, emul=self.dmask[1])
         jobs.append(ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"), db=GEg("net.4.bias"), defer=True))
-        ops.linear_dgrad(self.d_ez2, PE("net.4.weight"), self.d_ez1, gref=self.e_z1, gact=ACT_GELU, emul=self.dmask[0])
         jobs.append(ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"), db=GEg("net.1.bias"), defer=True))
-        ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
+        if self._chain_e:           # the encoder's data-gradient chain as one launch (feature_encoder.py:16-42 backwards)
+            ch = ops.Chain(B)
+            ch.load(0, self.d_gin[:, self.noise_dim:self.noise_dim + self.E])
+            ch.load(0, self.demb, accumulate=True)
+            ch.store(0, self.demb)
+            ch.linear_dgrad(0, 1, PE("net.7.weight"), gref=self.e_z2, gact=ACT_GELU, mask=self.dmask[1], out=self.d_ez2)
+            ch.linear_dgrad(1, 2, PE("net.4.weight"), gref=self.e_z1, gact=ACT_GELU, mask=self.dmask[0], out=self.d_ez1)
+            ch.linear_dgrad(2, 3, PE("net.1.weight"), out=self.d_ex0)
+            ch.launch()
+        else:
+            ops.copy_cols(self.d_gin, self.noise_dim, self.demb, 0, self.E, accumulate=True)
+            ops.linear_dgrad(self.demb, PE("net.7.weight"), self.d_ez2, gref=self.e_z2, gact=ACT_GELU, emul=self.dmask[1])
+            ops.linear_dgrad(self.d_ez2, PE("net.4.weight"), self.d_ez1, gref=self.e_z1, gact=ACT_GELU, emul=self.dmask[0])
+            ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
         ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
         ops.wgrad_multi(jobs)
 
@@ -1068,7 +1248,7 @@ class GanEngine:
         self.numeric.copy_(numeric)
         if latent is not None:
             self.latent.copy_(latent)
-        self._e_fwd(False, "g")
+        self._e_fwd(False, "g", gin=True)
         self._g_fwd(self.notes, False, "g")
         return self.notes
 

@@ -226,23 +226,7 @@ def conv16_poolable(B: int, Tin: int, Cin: int, N: int) -> bool:
 
 def conv16_pool(x: Tensor, wq: Tensor, y: Tensor, N: int, pool: Tensor, scale: float, **epi) -> Tensor:
     """conv16 (gather form) that also writes pool[b][n] = scale * sum_t y[b][t][n] (mg_conv16_pool)."""
-    _chk(x, "x")
-    _chk(wq, "wq")
-    _chk(y, "y")
-    B, Tin, Cin = x.shape
-    Tout = (Tin - 1) // 2 + 1
-    if tuple(y.shape) != (B, Tout, N):
-        raise ValueError(f"y: expected {(B, Tout, N)}, got {tuple(y.shape)}")
-    _chk(pool, "pool", (B, N))
-    e = epilogue((B, Tout, N), N, **epi)
-    lib = L.load()
-    def launch():
-        return lib.mg_conv16_pool(_p(x), _p(wq), _p(y), B, Tin, Cin, N, Tin * Cin, Tout * N, C.byref(e), _p(pool), float(scale),
-                                  _stream())
-    with _observe(lambda: "conv16_kernel<false,%d>" % (_conv16_plan(B, Tin, N, False)[2] // 32), 2.0 * B * Tout * N * Cin * 5, launch):
-        rc = launch()
-    L.check(rc, "mg_conv16_pool")
-    return y
+    return conv16(x, wq, y, N, False, pool=(pool, scale), **epi)
 
 
 def conv16_plan(B: int, Tin: int, N: int, transposed: bool):
@@ -256,35 +240,67 @@ def _conv16_plan(B, Tin, N, transposed):
     return tb.value, rows.value, bm.value
 
 
-def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool = False, stats=None, **epi) -> Tensor:
-    """Stride-2 K=5 window GEMM on 16x16 MFMA tiles with WQ-layout weights (mg_conv16).  transposed=False: the gather
+def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool = False, stats=None, pool=None,
+           perm: bool = False, mix=None, **epi) -> Tensor:
+    """Stride-2 K=5 window GEMM on 16x16 MFMA tiles with WQ-layout weights (mg_conv16_ex).  transposed=False: the gather
     form (Conv1d forward / ConvTranspose1d data-gradient), True: the scatter form (ConvTranspose1d forward / Conv1d
-    data-gradient; odd: Tout = 2*Tin - 1).  y: (B, Ty >= Tout, N).  stats: a float buffer that receives per-column partial
-    statistics (sum, sum of squares) of the stored values (mg_conv16_stats; size from conv16_plan)."""
+    data-gradient; odd: Tout = 2*Tin - 1).  y: (B, Ty >= Tout, N).  Riders of the same launch:
+      stats: a float buffer that receives per-column partial statistics (sum, centred sum of squares, count) of the stored
+             values (size 3 * part_rows * N from conv16_plan) for bn_train_fwd_parts;
+      pool = (tensor (B, N), scale): the temporal mean of the output (gather form, conv16_poolable shapes);
+      perm: y is (B, N, Tout) -- i.e. the (B, N*Tout) matrix a Linear produced and the reference views as (B, N, L);
+      mix = (real, alpha, out, rows): out[b] = alpha[b] * real[b] + (1 - alpha[b]) * y[b] for b < rows (tensors laid out
+            like y): the gradient penalty's interpolate."""
     _chk(x, "x")
     _chk(wq, "wq")
     _chk(y, "y")
     B, Tin, Cin = x.shape
     Tout = (2 * Tin - (1 if odd else 0)) if transposed else (Tin + 4 - 5) // 2 + 1
-    if y.dim() != 3 or y.shape[0] != B or y.shape[2] != N or y.shape[1] < Tout:
-        raise ValueError(f"y: expected (B={B}, >={Tout}, {N}), got {tuple(y.shape)}")
+    if perm:
+        if tuple(y.shape) != (B, N, Tout):
+            raise ValueError(f"y (perm): expected {(B, N, Tout)}, got {tuple(y.shape)}")
+        Ty = Tout
+    else:
+        if y.dim() != 3 or y.shape[0] != B or y.shape[2] != N or y.shape[1] < Tout:
+            raise ValueError(f"y: expected (B={B}, >={Tout}, {N}), got {tuple(y.shape)}")
+        Ty = y.shape[1]
     if wq.numel() != N * Cin * 5:
         raise ValueError(f"wq: numel {wq.numel()} != {N * Cin * 5}")
     e = epilogue((B, Tout, N), N, **epi)
-    if y.shape[1] != Tout and (e.zout or e.gref or e.emul):
+    if Ty != Tout and (e.zout or e.gref or e.emul):
         raise ValueError("padded y cannot be combined with elementwise epilogue tensors")
     lib = L.load()
     if not lib.mg_conv16_supported(B, Tin, Cin, N, 1 if transposed else 0, Tout):
         raise ValueError(f"conv16: unsupported shape B={B} Tin={Tin} Cin={Cin} N={N}")
-    part = None
+    ex = L.Conv16Extra()
     if stats is not None:
         part = _chk(stats, "stats")
-        if part.numel() < 2 * conv16_plan(B, Tin, N, transposed)[1] * N:
+        if part.numel() < 3 * conv16_plan(B, Tin, N, transposed)[1] * N:
             raise ValueError("conv16: partial-statistics buffer too small (conv16_plan)")
+        ex.part = _p(part)
+    if pool is not None:
+        pt, scale = pool
+        _chk(pt, "pool", (B, N))
+        if transposed or not lib.mg_conv16_poolable(B, Tin, Cin, N):
+            raise ValueError(f"conv16: shape B={B} Tin={Tin} Cin={Cin} N={N} is not poolable")
+        ex.pool, ex.pool_scale = _p(pt), float(scale)
+    ex.y_perm = 1 if perm else 0
+    if mix is not None:
+        real, alpha, out, rows = mix
+        if perm or not 0 < rows <= B:
+            raise ValueError("conv16: mix needs the plain output order and 0 < rows <= B")
+        for nm, t in (("mix real", real), ("mix out", out)):
+            _chk(t, nm)
+            if t.dim() != 3 or t.shape[0] < rows or tuple(t.shape[1:]) != (Ty, N):
+                raise ValueError(f"conv16: {nm} must be (>= {rows}, {Ty}, {N}), got {tuple(t.shape)}")
+        _chk(alpha, "mix alpha")
+        if alpha.numel() < rows:
+            raise ValueError("conv16: mix alpha has fewer entries than rows")
+        ex.mix_real, ex.mix_alpha, ex.mix_out, ex.mix_rows = _p(real), _p(alpha), _p(out), int(rows)
 
     def launch():
-        return lib.mg_conv16_stats(_p(x), _p(wq), _p(y), B, Tin, Cin, N, 1 if transposed else 0, Tout, Tin * Cin,
-                                   y.shape[1] * N, C.byref(e), _p(part), _stream())
+        return lib.mg_conv16_ex(_p(x), _p(wq), _p(y), B, Tin, Cin, N, 1 if transposed else 0, Tout, Tin * Cin, Ty * N, C.byref(e),
+                                C.byref(ex), _stream())
     sym = lambda: "conv16_kernel<%s,%d>" % ("true" if transposed else "false", _conv16_plan(B, Tin, N, transposed)[2] // 32)  # noqa: E731
     with _observe(sym, 2.0 * B * (Tin if transposed else Tout) * N * Cin * 5, launch):
         rc = launch()
@@ -295,26 +311,32 @@ def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool
 SKINNY_MAX_ROWS = 512      # Linear layers with at most this many rows use the skinny-GEMM kernel
 
 
-def _linear(x, w, y, K, N, w_sn, w_sc, epi):
+def _linear(x, w, y, K, N, w_sn, w_sc, epi, perm_L=0):
     M = x.shape[0]
     e = epilogue((M, N), N, **epi)
     lib = L.load()
     need = lib.mg_linear_workspace_bytes(M, N, K)
     work = workspace(need, x.device, "linear") if need else None
     with _observe(lambda: "linear_skinny_kernel", 2.0 * M * N * K):
-        rc = lib.mg_linear(_p(x), _p(w), _p(y), M, K, N, w_sn, w_sc, C.byref(e), _p(work),
-                           work.numel() if work is not None else 0, _stream())
+        rc = lib.mg_linear_perm(_p(x), _p(w), _p(y), M, K, N, w_sn, w_sc, C.byref(e), perm_L, _p(work),
+                                work.numel() if work is not None else 0, _stream())
     L.check(rc, "mg_linear")
     return y
 
 
-def linear_fwd(x, w, y, **epi):
-    """nn.Linear forward; x: (B, in), w: (out, in), y: (B, out)."""
+def linear_fwd(x, w, y, perm_L: int = 0, **epi):
+    """nn.Linear forward; x: (B, in), w: (out, in), y: (B, out).  perm_L > 0: y is (B, perm_L, out / perm_L) -- the
+    channels-last tensor behind the reference's view(B, C, L) + permute (mg_linear_perm); elementwise epilogue tensors are
+    laid out like y."""
     _chk(x, "x")
     _chk(w, "w")
     _chk(y, "y")
     out_f, in_f = w.shape
     B = x.shape[0]
+    if perm_L:
+        if B > SKINNY_MAX_ROWS or out_f % perm_L or x.dim() != 2 or x.shape[1] != in_f or tuple(y.shape) != (B, perm_L, out_f // perm_L):
+            raise ValueError(f"linear_fwd(perm_L={perm_L}): shape mismatch x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)}")
+        return _linear(x, w, y, in_f, out_f, in_f, 1, epi, perm_L)
     if x.dim() != 2 or x.shape[1] != in_f or tuple(y.shape) != (B, out_f):
         raise ValueError(f"linear_fwd: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)}")
     if B <= SKINNY_MAX_ROWS:
@@ -336,6 +358,180 @@ def linear_dgrad(dy, w, dx, **epi):
         return _linear(dy, w, dx, out_f, in_f, 1, in_f, epi)
     conv_gather(dy.view(B, 1, out_f), w, dx.view(B, 1, in_f), in_f, 1, 1, 1, in_f, **epi)
     return dx
+
+
+# ---------------------------------------------------------------------------------------
+# row chains: a sample's small layer stack in one launch (csrc/row_chain.hip)
+# ---------------------------------------------------------------------------------------
+class Chain:
+    """Builder for mg_row_chain: ops over LDS vector slots (L.CHAIN_SLOTS slots of up to L.CHAIN_MAX_VEC floats), one
+    workgroup per row.  Row tensors are 2-D float32 device tensors with unit column stride (column blocks of wider
+    matrices are fine: the row stride is taken from the tensor).  launch() enqueues on the current stream."""
+
+    def __init__(self, rows: int):
+        self.rows, self.ops, self._keep = int(rows), [], []
+
+    @staticmethod
+    def supported(*dims) -> bool:
+        """Every vector length of the chain fits a slot."""
+        return all(0 < int(d) <= L.CHAIN_MAX_VEC for d in dims)
+
+    @staticmethod
+    def weights_ok(*ws) -> bool:
+        """Weight matrices a chain can read: contiguous (N, K); rows 16-byte aligned wherever the 16-byte path applies."""
+        for w in ws:
+            if w.dim() != 2 or not w.is_contiguous() or w.dtype != torch.float32:
+                return False
+            if w.shape[1] >= 16 and w.shape[1] % 4 == 0 and w.data_ptr() % 16:
+                return False
+        return True
+
+    def _rows(self, t, name, n, rows=None, dtype=torch.float32):
+        rows = self.rows if rows is None else rows
+        if (not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1 or
+                t.shape[0] < rows or t.shape[1] < n or (t.shape[0] > 1 and t.stride(0) < t.shape[1])):
+            raise ValueError(f"chain {name}: expected a (>= {rows}, >= {n}) float32 device tensor with unit column stride")
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr()), t.stride(0)
+
+    def _vec(self, t, name, n):
+        _chk(t, name)
+        if t.numel() < n:
+            raise ValueError(f"chain {name}: needs {n} elements")
+        self._keep.append(t)
+        return C.c_void_p(t.data_ptr())
+
+    def _op(self, kind, a=0, b=0, n0=0, n1=0):
+        if len(self.ops) >= L.CHAIN_MAX_OPS:
+            raise ValueError(f"chain: more than {L.CHAIN_MAX_OPS} ops")
+        for s_ in (a, b):
+            if not 0 <= s_ < L.CHAIN_SLOTS:
+                raise ValueError("chain: slot out of range")
+        for n in (n0, n1):
+            if n > L.CHAIN_MAX_VEC:
+                raise ValueError(f"chain: vector of {n} floats exceeds a slot ({L.CHAIN_MAX_VEC})")
+        o = L.ChainOp()
+        o.kind, o.a, o.b, o.n0, o.n1 = kind, a, b, n0, n1
+        self.ops.append(o)
+        return o
+
+    def load(self, slot, t, n=None, accumulate=False, mod=0):
+        n = t.shape[1] if n is None else n
+        o = self._op(L.CH_LOAD, b=slot, n0=n)
+        o.p0, o.ld0 = self._rows(t, "load", n, rows=mod or None)
+        o.i0, o.i1 = (1 if accumulate else 0), int(mod)
+        return self
+
+    def store(self, slot, t, n=None):
+        n = t.shape[1] if n is None else n
+        o = self._op(L.CH_STORE, a=slot, n0=n)
+        o.q0, o.lq0 = self._rows(t, "store", n)
+        return self
+
+    def mean_t(self, slot, x, out=None):
+        """slot = mean over time of x (rows, T, C) contiguous."""
+        _chk(x, "mean_t x")
+        if x.dim() != 3 or x.shape[0] < self.rows:
+            raise ValueError("chain mean_t: x must be (>= rows, T, C)")
+        self._keep.append(x)
+        o = self._op(L.CH_MEAN_T, b=slot, n0=x.shape[2])
+        o.p0, o.ld0, o.i0 = C.c_void_p(x.data_ptr()), x.shape[2], x.shape[1]
+        if out is not None:
+            o.q0, o.lq0 = self._rows(out, "mean_t out", x.shape[2])
+        return self
+
+    def layernorm(self, a, b, gamma, beta, xhat=None, y=None, eps=1e-5):
+        D = gamma.numel()
+        o = self._op(L.CH_LAYERNORM, a=a, b=b, n0=D)
+        o.p0, o.p1, o.f0 = self._vec(gamma, "gamma", D), self._vec(beta, "beta", D), float(eps)
+        if xhat is not None:
+            o.q0, o.lq0 = self._rows(xhat, "xhat", D)
+        if y is not None:
+            o.q1, o.lq1 = self._rows(y, "ln out", D)
+        return self
+
+    def linear_fwd(self, a, b, w, bias=None, act=ACT_NONE, mask=None, zout=None, out=None):
+        """slot b = act(slot a @ w.T + bias) * mask;  w: (N, K) contiguous."""
+        _chk(w, "w")
+        N, K = w.shape
+        self._keep.append(w)
+        o = self._op(L.CH_LIN_FWD, a=a, b=b, n0=K, n1=N)
+        o.p0, o.ld0, o.act = C.c_void_p(w.data_ptr()), K, act
+        if bias is not None:
+            o.p1 = self._vec(bias, "bias", N)
+        if mask is not None:
+            o.p2, o.ld2 = self._rows(mask, "mask", N)
+        if zout is not None:
+            o.q0, o.lq0 = self._rows(zout, "zout", N)
+        if out is not None:
+            o.q1, o.lq1 = self._rows(out, "out", N)
+        return self
+
+    def linear_dgrad(self, a, b, w, gref=None, gact=ACT_NONE, mask=None, out=None):
+        """slot b = (slot a @ w) * act'(gref) * mask;  w: (OUT, IN) contiguous."""
+        _chk(w, "w")
+        OUT, IN = w.shape
+        self._keep.append(w)
+        o = self._op(L.CH_LIN_DGRAD, a=a, b=b, n0=OUT, n1=IN)
+        o.p0, o.ld0, o.act = C.c_void_p(w.data_ptr()), IN, gact
+        if gref is not None:
+            o.p1, o.ld1 = self._rows(gref, "gref", IN)
+        if mask is not None:
+            o.p2, o.ld2 = self._rows(mask, "mask", IN)
+        if out is not None:
+            o.q1, o.lq1 = self._rows(out, "out", IN)
+        return self
+
+    def softmax_ce(self, a, b, target, loss_rows, scale, n_classes):
+        """Per row: loss_rows[r] = CE(logits in slot a, target[r]); slot b = scale * (softmax - onehot)."""
+        _chk(target, "target", dtype=torch.int64)
+        _chk(loss_rows, "loss_rows")
+        if target.numel() < self.rows or loss_rows.numel() < self.rows or not 0 < n_classes <= 32:
+            raise ValueError("chain softmax_ce: sizes")
+        self._keep += [target, loss_rows]
+        o = self._op(L.CH_SOFTMAX_CE, a=a, b=b, n0=n_classes)
+        o.t0, o.q0, o.f0 = C.c_void_p(target.data_ptr()), C.c_void_p(loss_rows.data_ptr()), float(scale)
+        return self
+
+    def dhead(self, a, b, w, bias, emb, ds, s, demb=None):
+        """Critic head on slot a = f (F): s[r] = f . w[:F] + emb[r % Be] . w[F:] + bias; slot b = ds[r] * w[:F] * lrelu'(f);
+        demb rows <- ds[r] * w[F:] (needs one embedding row per sample)."""
+        _chk(w, "w")
+        _chk(bias, "bias")
+        _chk(ds, "ds")
+        _chk(s, "s")
+        E = emb.shape[1] if emb is not None else 0
+        F = w.numel() - E
+        if F <= 0 or ds.numel() < self.rows or s.numel() < self.rows:
+            raise ValueError("chain dhead: sizes")
+        self._keep += [w, bias, ds, s]
+        o = self._op(L.CH_DHEAD, a=a, b=b, n0=F, n1=E)
+        o.p0, o.p1, o.p3, o.q0 = C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(ds.data_ptr()), C.c_void_p(s.data_ptr())
+        if emb is not None:
+            Be = emb.shape[0]
+            o.p2, o.ld2 = self._rows(emb, "emb", E, rows=Be)
+            o.i1 = Be
+            if demb is not None:
+                if Be != self.rows:
+                    raise ValueError("chain dhead: the embedding gradient needs one embedding row per sample")
+                o.q1, o.lq1 = self._rows(demb, "demb", E)
+        return self
+
+    def launch(self):
+        arr = (L.ChainOp * len(self.ops))(*self.ops)
+        flops = 0.0
+        for o in self.ops:
+            if o.kind in (L.CH_LIN_FWD, L.CH_LIN_DGRAD):
+                flops += 2.0 * self.rows * o.n0 * o.n1
+        with _observe(lambda: "row_chain_kernel", flops):
+            rc = L.load().mg_row_chain(arr, len(self.ops), self.rows, _stream())
+        L.check(rc, "mg_row_chain")
+
+
+def mean_scaled(src, out, scale=1.0):
+    _chk(src, "src")
+    _chk(out, "out")
+    L.check(L.load().mg_mean_scaled(_p(src), _p(out), src.numel(), float(scale), _stream()), "mg_mean_scaled")
 
 
 # ---------------------------------------------------------------------------------------
@@ -613,13 +809,13 @@ def bn_train_fwd(z, a, gamma, beta, running_mean, running_var, save_mean, save_i
 def bn_train_fwd_parts(part, part_rows, groups, z, a, gamma, beta, running_mean, running_var, save_mean, save_invstd,
                        act=ACT_RELU, momentum=0.1, eps=1e-5):
     """bn_train_fwd from the partial column statistics the producing conv16 launch left in `part` (part_rows rows in
-    all, part_rows / groups per group): finish the statistics and move the running ones (one small launch), apply."""
+    all, part_rows / groups per group): statistics, running statistics and the apply pass in ONE launch."""
     _chk(z, "z")
     _chk(a, "a", z.shape)
     _chk(part, "part")
     Cc = z.shape[-1]
     R = z.numel() // Cc
-    if groups < 1 or z.shape[0] % groups or part_rows % groups or part.numel() < 2 * part_rows * Cc:
+    if groups < 1 or z.shape[0] % groups or part_rows % groups or part.numel() < 3 * part_rows * Cc:
         raise ValueError("bn_train_fwd_parts: groups / partial rows do not fit")
     for nm, v in (("gamma", gamma), ("beta", beta)):
         _chk(v, nm, (Cc,))
@@ -684,7 +880,8 @@ def meanT_fwd(a, h):
     return h
 
 
-def meanT_bwd(dh, dz, gref=None, gact=ACT_NONE, gscale=None):
+def meanT_bwd(dh, dz, gref=None, gact=ACT_NONE, gscale=None, mean=None):
+    """mean = (src, out, scale): out[0] = scale * mean(src) rides in the same launch (mg_meanT_bwd_mean)."""
     _chk(dz, "dz")
     B, T, Cc = dz.shape
     _chk(dh, "dh", (B, Cc))
@@ -692,7 +889,17 @@ def meanT_bwd(dh, dz, gref=None, gact=ACT_NONE, gscale=None):
         _chk(gref, "gref", dz.shape)
     if gscale is not None:
         _chk(gscale, "gscale", (Cc,))
-    L.check(L.load().mg_meanT_bwd(_p(dh), _p(dz), B, T, Cc, _p(gref), gact, _p(gscale), _stream()), "mg_meanT_bwd")
+    msrc = mout = None
+    mn, msc = 0, 0.0
+    if mean is not None:
+        msrc, mout, msc = mean
+        _chk(msrc, "mean src")
+        _chk(mout, "mean out")
+        mn = msrc.numel()
+        if mn < 1 or mout.numel() < 1:
+            raise ValueError("meanT_bwd: empty mean rider")
+    L.check(L.load().mg_meanT_bwd_mean(_p(dh), _p(dz), B, T, Cc, _p(gref), gact, _p(gscale), _p(msrc), _p(mout), mn, float(msc),
+                                       _stream()), "mg_meanT_bwd")
     return dz
 
 
@@ -774,7 +981,8 @@ def dhead_bwd(ds, f, w, dU, demb=None, nb_emb=0):
             "mg_dhead_bwd")
 
 
-def dhead_wgrad(ds, f, emb, gf, dw, dbias, nb, ng):
+def dhead_wgrad(ds, f, emb, gf, dw, dbias, nb, ng, loss=None):
+    """loss = (s, norms, lambda_gp, out, gp_out, nb): the critic's loss scalars (wgan_d_loss with norms) ride in the same launch."""
     _chk(f, "f")
     F = f.shape[1]
     Be, E = (emb.shape if emb is not None else (0, 0))
@@ -784,8 +992,17 @@ def dhead_wgrad(ds, f, emb, gf, dw, dbias, nb, ng):
     if dw.numel() != F + E:
         raise ValueError("dhead_wgrad: dw size mismatch")
     _chk(dbias, "dbias")
-    L.check(L.load().mg_dhead_wgrad(_p(ds), _p(f), _p(emb), _p(gf), _p(dw), _p(dbias), nb, ng if gf is not None else 0,
-                                    Be, F, E, _stream()), "mg_dhead_wgrad")
+    ls = ln = lo = lg = None
+    lam, lnb = 0.0, 0
+    if loss is not None:
+        ls, ln, lam, lo, lg, lnb = loss
+        _chk(ls, "loss s")
+        _chk(ln, "loss norms", (lnb,))
+        _chk(lg, "gp_out")
+        if ls.numel() < 2 * lnb or lo.numel() < 3 or lnb < 1:
+            raise ValueError("dhead_wgrad: loss rider sizes")
+    L.check(L.load().mg_dhead_wgrad_loss(_p(ds), _p(f), _p(emb), _p(gf), _p(dw), _p(dbias), nb, ng if gf is not None else 0,
+                                         Be, F, E, _p(ls), _p(ln), float(lam), _p(lo), _p(lg), lnb, _stream()), "mg_dhead_wgrad")
 
 
 def gp_interp(real, fake, alpha, xhat):
@@ -869,13 +1086,17 @@ def copy_cols(src, soff, dst, doff, ncols, accumulate=False):
 
 
 def stage_rows(jobs, n_rows):
-    """Batch staging in ONE launch: for every (src, dst, idx) in `jobs`, dst[r] = src[idx[r] if idx is not None else r]
-    for r < n_rows.  src/dst: contiguous device tensors of one dtype whose rows (dim 0) have equal byte size; idx: int64
+    """Batch staging in ONE launch: for every (src, dst, idx[, rows]) in `jobs`, dst[r] = src[idx[r] if idx is not None else r]
+    for r < rows (default n_rows, the launch's row count).  src/dst: contiguous device tensors of one dtype whose rows (dim 0) have equal byte size; idx: int64
     device tensor of n_rows entries (clamped into the source on the device)."""
     if not 0 < len(jobs) <= L.MAX_STAGE_JOBS:
         raise ValueError(f"stage_rows: 1..{L.MAX_STAGE_JOBS} jobs")
     arr = (L.StageJob * len(jobs))()
-    for a, (src, dst, idx) in zip(arr, jobs):
+    for a, job in zip(arr, jobs):
+        src, dst, idx = job[:3]
+        jrows = job[3] if len(job) > 3 else n_rows
+        if not 0 < jrows <= n_rows:
+            raise ValueError("stage_rows: a job's row count must be in 1..n_rows")
         if not isinstance(src, torch.Tensor) or not src.is_cuda or not src.is_contiguous() or src.dim() < 1:
             raise ValueError("stage_rows: src must be a contiguous device tensor")
         # dst: dense, or a column block of a wider 2-D matrix (rows contiguous, a row pitch between them)
@@ -884,16 +1105,17 @@ def stage_rows(jobs, n_rows):
                  dst.stride(0) >= dst.shape[1])
         if not (dense or block):
             raise ValueError("stage_rows: dst must be a contiguous device tensor or a column block of one")
-        if src.dtype != dst.dtype or src.shape[1:] != dst.shape[1:] or dst.shape[0] < n_rows:
+        if src.dtype != dst.dtype or src.shape[1:] != dst.shape[1:] or dst.shape[0] < jrows:
             raise ValueError(f"stage_rows: row mismatch {tuple(src.shape)} {src.dtype} -> {tuple(dst.shape)} {dst.dtype}")
         if idx is not None:
-            _chk(idx, "idx", (n_rows,), torch.int64)
-        elif src.shape[0] < n_rows:
+            _chk(idx, "idx", (jrows,), torch.int64)
+        elif src.shape[0] < jrows:
             raise ValueError("stage_rows: source has fewer rows than the batch")
         row_bytes = src.element_size() * (src[0].numel() if src.dim() > 1 else 1)
         a.src, a.dst, a.idx = src.data_ptr(), dst.data_ptr(), (None if idx is None else idx.data_ptr())
         a.row_bytes, a.src_rows = row_bytes, src.shape[0]
         a.dst_pitch = 0 if dense else dst.stride(0) * dst.element_size()
+        a.rows = 0 if jrows == n_rows else jrows
     L.check(L.load().mg_stage_rows(arr, len(jobs), n_rows, _stream()), "mg_stage_rows")
 
 

@@ -113,7 +113,7 @@ def test_batchnorm_from_the_convolutions_partial_statistics(ops, B, L, Cin, Cout
     wq = wq_of(ops, w, Cout, Cin, 5, Cout * 5)
     tb, rows = ops.conv16_plan(B, L, Cout, True)
     assert (B // groups) % tb == 0
-    part = torch.full((2 * rows * Cout,), float("nan"), device="cuda")
+    part = torch.full((3 * rows * Cout,), float("nan"), device="cuda")
     z = torch.empty(B, 2 * L, Cout, device="cuda")
     ops.conv16(x.cuda(), wq, z, Cout, True, bias=bias.cuda(), stats=part)
     a1, a2 = torch.empty_like(z), torch.empty_like(z)
@@ -147,7 +147,7 @@ def test_conv16_pool_is_the_temporal_mean_of_the_output(B, Tin, Cin, N):
     assert ops.conv16_poolable(B, Tin, Cin, N) == (Tout == 32)
     y, pool = torch.empty(B, Tout, N, device="cuda"), torch.full((B, N), float("nan"), device="cuda")
     if Tout != 32:
-        with pytest.raises(RuntimeError):
+        with pytest.raises((RuntimeError, ValueError)):
             ops.conv16_pool(x, wq, y, N, pool, 1.0 / Tout, bias=b, act=ops.ACT_LRELU)
         return
     ops.conv16_pool(x, wq, y, N, pool, 1.0 / Tout, bias=b, act=ops.ACT_LRELU)
@@ -158,3 +158,91 @@ def test_conv16_pool_is_the_temporal_mean_of_the_output(B, Tin, Cin, N):
     ref = torch.randn(B, Tout, N, generator=g).cuda()
     ops.conv16_pool(x, wq, y, N, pool, 1.0 / Tout, gref=ref, gact=ops.ACT_LRELU)
     torch.testing.assert_close(pool, y.double().mean(dim=1).float(), rtol=1e-5, atol=1e-6)
+
+
+def test_batchnorm_statistics_keep_their_digits_under_a_large_channel_offset(ops):
+    """The partial statistics are centred per wave and combined by the parallel-variance rule: a channel whose mean is
+    1000x its deviation (bias 300, deviation ~0.3) still gets invstd / running_var to fp32 accuracy.  (E[x^2] - mean^2
+    from fp32 sums of squares loses ~1e-6 * mean^2 / var = 1 of the variance here.)"""
+    B, L, Cin, Cout = 64, 32, 64, 64
+    x, w = rnd(B, L, Cin, seed=1), rnd(Cin, Cout, 5, seed=2, scale=0.02)
+    bias = torch.full((Cout,), 300.0)
+    bias[::2] = -75.0
+    gamma, beta = torch.ones(Cout), torch.zeros(Cout)
+    wq = wq_of(ops, w, Cout, Cin, 5, Cout * 5)
+    tb, rows = ops.conv16_plan(B, L, Cout, True)
+    part = torch.full((3 * rows * Cout,), float("nan"), device="cuda")
+    z = torch.empty(B, 2 * L, Cout, device="cuda")
+    ops.conv16(x.cuda(), wq, z, Cout, True, bias=bias.cuda(), stats=part)
+    a = torch.empty_like(z)
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    m, i = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    ops.bn_train_fwd_parts(part, rows, 1, z, a, gamma.cuda(), beta.cuda(), rm, rv, m, i, ops.ACT_NONE)
+    z64 = z.cpu().double().view(-1, Cout)
+    mean, var = z64.mean(0), z64.var(0, unbiased=False)
+    assert float((mean.abs() / var.sqrt()).min()) > 100
+    torch.testing.assert_close(m.cpu().double(), mean, rtol=1e-6, atol=0)
+    torch.testing.assert_close(i.cpu().double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5, atol=0)
+    torch.testing.assert_close(rv.cpu().double(), 0.9 + 0.1 * z64.var(0, unbiased=True), rtol=2e-5, atol=0)
+    ref = (z64 - mean) / torch.sqrt(var + 1e-5)
+    assert float((a.cpu().double().view(-1, Cout) - ref).abs().max()) < 2e-3      # z itself carries 300 * 2^-24 of rounding per element
+
+
+@pytest.mark.parametrize("B,Tin,Cin,N", [(64, 64, 128, 256), (3, 16, 32, 64)])
+def test_permuted_output_order_equals_a_transpose(ops, B, Tin, Cin, N):
+    """perm: the gather form writes (B, N, Tout) -- decoder.pre.2's (B, 256*L) output order behind view(B, 256, L)
+    (src/gan/models.py:70) -- with the elementwise epilogue operand still in the dense (B, Tout, N) order."""
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, Tin, Cin, generator=g).cuda()
+    w = (torch.randn(N, Cin, 5, generator=g) * 0.05).cuda()
+    wq = wq_of(ops, w.cpu(), N, Cin, Cin * 5, 5)
+    Tout = (Tin - 1) // 2 + 1
+    gref = torch.randn(B, Tout, N, generator=g).cuda()
+    dense = torch.empty(B, Tout, N, device="cuda")
+    ops.conv16(x, wq, dense, N, False, gref=gref, gact=ops.ACT_RELU)
+    perm = torch.full((B, N, Tout), float("nan"), device="cuda")
+    ops.conv16(x, wq, perm, N, False, perm=True, gref=gref, gact=ops.ACT_RELU)
+    assert torch.equal(perm, dense.permute(0, 2, 1).contiguous())
+
+
+def test_gradient_penalty_interpolate_rides_in_the_producing_launch(ops):
+    """mix: the launch that stores the fake batch also writes x_hat = alpha * real + (1 - alpha) * fake for the first
+    mix_rows samples (src/gan/utils.py:76-79); equal to mg_gp_interp of the stored values; other rows untouched."""
+    B, L, Cin, N, rows = 8, 16, 64, 128, 4
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, L, Cin, generator=g).cuda()
+    w = torch.randn(Cin, N, 5, generator=g) * 0.05
+    wq = wq_of(ops, w, N, Cin, 5, N * 5)
+    bias = torch.randn(N, generator=g).cuda()
+    real = torch.randn(rows, 2 * L, N, generator=g).cuda()
+    alpha = torch.rand(rows, generator=g).cuda()
+    y = torch.empty(B, 2 * L, N, device="cuda")
+    out = torch.full((B, 2 * L, N), 7.0, device="cuda")
+    ops.conv16(x, wq, y, N, True, bias=bias, mix=(real, alpha, out, rows))
+    y2 = torch.empty_like(y)
+    ops.conv16(x, wq, y2, N, True, bias=bias)
+    assert torch.equal(y, y2)
+    want = torch.empty(rows, 2 * L, N, device="cuda")
+    ops.gp_interp(real, y[:rows].contiguous(), alpha, want)
+    assert torch.equal(out[:rows], want) and bool((out[rows:] == 7.0).all())
+    a = alpha.view(-1, 1, 1)
+    torch.testing.assert_close(out[:rows], a * real + (1 - a) * y[:rows], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,K,Cc,Lp", [(128, 512, 256, 32), (64, 512, 256, 32), (3, 40, 8, 4)])
+def test_linear_with_permuted_output_columns(ops, M, K, Cc, Lp):
+    """mg_linear_perm: the Linear output lands as (M, L, C) = view(M, C, L).permute(0, 2, 1) of the reference order
+    (src/gan/models.py:70-73), bias and activation included, elementwise operands in the stored order."""
+    g = torch.Generator().manual_seed(M)
+    N = Cc * Lp
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ref = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(x, w, ref, bias=b, act=ops.ACT_RELU)
+    y = torch.full((M, Lp, Cc), float("nan"), device="cuda")
+    z = torch.full((M, Lp, Cc), float("nan"), device="cuda")
+    ops.linear_fwd(x, w, y, perm_L=Lp, bias=b, act=ops.ACT_RELU, zout=z)
+    assert torch.equal(y, ref.view(M, Cc, Lp).permute(0, 2, 1).contiguous())
+    ops.linear_fwd(x, w, ref, bias=b)
+    assert torch.equal(z, ref.view(M, Cc, Lp).permute(0, 2, 1).contiguous())

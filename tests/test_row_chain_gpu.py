@@ -1,0 +1,185 @@
+"""Row chains (csrc/row_chain.hip): a sample's small layer stack as one launch, against plain PyTorch fp32 references of
+the same ops (ragged and maximal vector lengths, both code paths of each op) and -- at the engine level -- against the
+per-layer launches they replace (MELO_CHAINS=0), at a fixture size and at cfg2."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import melo_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale)
+
+
+def close(got, ref, tol=1e-5):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = float((got - ref).norm() / (ref.norm() + 1e-30))
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("rows,K,N,act", [(64, 256, 256, 3), (5, 6, 256, 3), (7, 128, 4, 0), (3, 512, 100, 2), (9, 20, 33, 1),
+                                          (2, 18, 5, 0), (192, 256, 256, 2)])
+def test_linear_forward_and_data_gradient(ops, rows, K, N, act):
+    x, w, b = rnd(rows, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    mask = (torch.rand(rows, N, generator=torch.Generator().manual_seed(4)) > 0.2).float() / 0.8
+    acts = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: F.gelu}
+    z_ref = x @ w.t() + b
+    y_ref = acts[act](z_ref) * mask
+    z, y = torch.full((rows, N), float("nan"), device="cuda"), torch.full((rows, N + 3), float("nan"), device="cuda")
+    dy = rnd(rows, N, seed=5)
+    xg = x.clone().requires_grad_(True)
+    (acts[act](xg @ w.t() + b) * mask * dy).sum().backward()
+    # dgrad through the chain: dx = ((dy * mask * act'(z)) @ w): feed dy, apply act' / mask on the OUTPUT side of a second layer
+    dx = torch.full((rows, K), float("nan"), device="cuda")
+    ch = ops.Chain(rows)
+    ch.load(0, x.cuda())
+    ch.linear_fwd(0, 1, w.cuda(), b.cuda(), act, mask.cuda(), zout=z, out=y[:, 3:])     # a column block as destination
+    ch.launch()
+    close(z, z_ref)
+    close(y[:, 3:], y_ref)
+    assert torch.isnan(y[:, :3]).all()
+    g_in = (dy * mask).cuda()        # upstream gradient at the activation output
+    if act == 1:
+        gref = F.relu(z_ref)
+    elif act == 2:
+        gref = F.leaky_relu(z_ref, 0.2)
+    else:
+        gref = z_ref
+    # dz = g_in * act'(gref): as a data-gradient op through the identity-like weight is awkward; do it via act_bwd, then the chain's dgrad
+    dz = torch.empty(rows, N, device="cuda")
+    ops.act_bwd(g_in, dz, gref=gref.cuda() if act else None, gact=act)
+    ch = ops.Chain(rows)
+    ch.load(2, dz)
+    ch.linear_dgrad(2, 3, w.cuda(), out=dx)
+    ch.launch()
+    close(dx, xg.grad, 2e-5)
+
+
+def test_dgrad_epilogue_gref_and_mask(ops):
+    rows, OUT, IN = 11, 128, 256
+    dy, w, zprev = rnd(rows, OUT, seed=1), rnd(OUT, IN, seed=2, scale=0.1), rnd(rows, IN, seed=3)
+    mask = (torch.rand(rows, IN, generator=torch.Generator().manual_seed(4)) > 0.2).float() / 0.8
+    zp = zprev.clone().requires_grad_(True)
+    ((F.gelu(zp) * mask) @ w.t() * dy).sum().backward()
+    out = torch.empty(rows, IN, device="cuda")
+    ch = ops.Chain(rows)
+    ch.load(0, dy.cuda()).linear_dgrad(0, 1, w.cuda(), gref=zprev.cuda(), gact=ops.ACT_GELU, mask=mask.cuda(), out=out).launch()
+    close(out, zp.grad, 2e-5)
+
+
+def test_layernorm_mean_t_ce_and_dhead(ops):
+    rows, D = 9, 6
+    x, g, b = rnd(rows, D, seed=1), rnd(D, seed=2).abs() + 0.5, rnd(D, seed=3)
+    y, xh = torch.empty(rows, D, device="cuda"), torch.empty(rows, D, device="cuda")
+    ops.Chain(rows).load(0, x.cuda()).layernorm(0, 1, g.cuda(), b.cuda(), xhat=xh, y=y).launch()
+    close(y, F.layer_norm(x, (D,), g, b, 1e-5))
+    close(xh, F.layer_norm(x, (D,), None, None, 1e-5))
+    # mean over time
+    a = rnd(rows, 37, 100, seed=4)
+    pool = torch.empty(rows, 100, device="cuda")
+    ops.Chain(rows).mean_t(0, a.cuda(), out=pool).launch()
+    close(pool, a.mean(1))
+    # cross-entropy rows + gradient, out-of-range target poisons its row only
+    Cc, Bt = 4, rows
+    logits = rnd(rows, Cc, seed=5)
+    tgt = torch.randint(0, Cc, (rows,), generator=torch.Generator().manual_seed(6))
+    lg = logits.clone().requires_grad_(True)
+    loss = F.cross_entropy(lg, tgt)
+    loss.backward()
+    lrows, dl = torch.empty(rows, device="cuda"), torch.empty(rows, Cc, device="cuda")
+    ch = ops.Chain(rows)
+    ch.load(0, logits.cuda()).softmax_ce(0, 1, tgt.cuda(), lrows, 5.0 / Bt, Cc).store(1, dl).launch()
+    close(lrows.mean(), loss)
+    close(dl, 5.0 * lg.grad, 2e-5)
+    bad = tgt.clone()
+    bad[2] = Cc
+    ch = ops.Chain(rows)
+    ch.load(0, logits.cuda()).softmax_ce(0, 1, bad.cuda(), lrows, 1.0, Cc).store(1, dl).launch()
+    assert torch.isnan(lrows[2]) and torch.isnan(dl[2]).all() and torch.isfinite(dl[3:]).all() and torch.isfinite(lrows[:2]).all()
+    # critic head: against mg_dhead_fwd_bwd
+    nb, Be, Fd, E = 12, 4, 256, 128
+    f, emb, w, bias, ds = rnd(nb, Fd, seed=7), rnd(Be, E, seed=8), rnd(Fd + E, seed=9), rnd(1, seed=10), rnd(nb, seed=11)
+    s1, dU1 = torch.empty(nb, device="cuda"), torch.empty(nb, Fd, device="cuda")
+    ops.dhead_fwd_bwd(ds.cuda(), f.cuda(), emb.cuda(), w.cuda(), bias.cuda(), s1, dU1, None)
+    s2, dU2 = torch.empty(nb, device="cuda"), torch.empty(nb, Fd, device="cuda")
+    ops.Chain(nb).load(0, f.cuda()).dhead(0, 1, w.cuda(), bias.cuda(), emb.cuda(), ds.cuda(), s2).store(1, dU2).launch()
+    close(s2, s1)
+    assert torch.equal(dU1, dU2)
+    emb4, demb1, demb2 = rnd(nb, E, seed=12), torch.empty(nb, E, device="cuda"), torch.empty(nb, E, device="cuda")
+    ops.dhead_fwd_bwd(ds.cuda(), f.cuda(), emb4.cuda(), w.cuda(), bias.cuda(), s1, dU1, demb1, nb_emb=nb)
+    ops.Chain(nb).load(0, f.cuda()).dhead(0, 1, w.cuda(), bias.cuda(), emb4.cuda(), ds.cuda(), s2, demb=demb2).launch()
+    close(s2, s1)
+    close(demb2, demb1)
+
+
+def test_bad_chains_are_refused_on_the_host(ops):
+    ch = ops.Chain(4)
+    with pytest.raises(ValueError):
+        ch.load(0, torch.zeros(4, 600, device="cuda"))                 # longer than a slot
+    with pytest.raises(ValueError):
+        ch.load(9, torch.zeros(4, 8, device="cuda"))                   # no such slot
+    with pytest.raises(ValueError):
+        ch.load(0, torch.zeros(2, 8, device="cuda"))                   # fewer rows than the chain
+    with pytest.raises(ValueError):
+        ch.load(0, torch.zeros(4, 8))                                  # host tensor
+    ch = ops.Chain(4)
+    ch.load(0, torch.zeros(4, 16, device="cuda")).linear_fwd(0, 0, torch.zeros(8, 16, device="cuda"))     # in place
+    with pytest.raises(RuntimeError):
+        ch.launch()
+
+
+def _engine(chains, B, T, C, seed=3):
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.gan.engine import GanEngine
+    os.environ["MELO_CHAINS"] = "1" if chains else "0"
+    try:
+        cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
+        S = O.build_gan_state(cfg, ed_cfg, "weights_init", seed=seed)
+        for k in S.PD:
+            S.PD[k].mul_(8.0 if k.endswith("weight") else 1.0)
+        eng = GanEngine(cfg, ed_cfg, "cuda", B)
+    finally:
+        os.environ.pop("MELO_CHAINS", None)
+    eng.load_state(S.PE, S.PG, S.BG, S.PD, S.PED, S.BED)
+    batch = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 42)
+    eng.set_batch(*(t.cuda() for t in batch))
+    R = O.step_randoms(B, cfg["NOISE_DIM"], seed=9)
+    eng.set_randoms(R["noise_d"].cuda(), [m.cuda() for m in R["dm_d"]], R["alpha"].cuda())
+    eng.set_randoms(R["noise_g"].cuda(), [m.cuda() for m in R["dm_g"]])
+    return eng
+
+
+@pytest.mark.parametrize("B,T,C", [(4, 64, 128), (64, 256, 128), (4, 32, 4)])
+def test_engine_with_chains_equals_the_per_layer_launches(B, T, C):
+    """The full fused step with the three chains against the same step on per-layer launches: same losses, gradients,
+    activations to fp32 summation-order accuracy."""
+    e1, e0 = _engine(True, B, T, C), _engine(False, B, T, C)
+    assert e1._chain_e and e1._chain_d and e1._chain_ed and not (e0._chain_e or e0._chain_d or e0._chain_ed)
+    for e in (e1, e0):
+        e.dg_forward()
+        e.d_backward(forward=False)
+        e.d_update()
+        e.g_backward_a2()
+        e.g_backward_b()
+    torch.cuda.synchronize()
+    for name in ("emb_2", "gin_2", "e_z1_2", "e_h2_2", "Fh", "s", "dU", "dH", "logits", "dlogits", "ed_pool", "ed_proj", "ed_dpool",
+                 "demb", "d_ez2", "d_ez1", "d_ex0", "loss_d_out", "adv", "emo", "notes", "dnotes"):
+        a, b = getattr(e1, name), getattr(e0, name)
+        close(a, b, 2e-5)
+    close(e1.D.grad, e0.D.grad, 2e-5)
+    for k, (o, n) in e1.GE.offsets.items():
+        if k in ("G.decoder.deconv.0.bias", "G.decoder.deconv.3.bias"):
+            continue
+        close(e1.GE.grad[o:o + n], e0.GE.grad[o:o + n], 1e-3 if B < 16 else 1e-4)
