@@ -340,7 +340,7 @@ def main():
 
     def barrier():
         if dist_on:
-            # this script's own collectives stay off the engine's stream (async_op + wait): see ops._quiesce_process_group
+            # this script's own collectives stay off the engine's stream (async_op + wait on the process group's stream)
             dist.barrier(async_op=True).wait()
 
     with torch.cuda.stream(eng.stream):
@@ -509,7 +509,8 @@ def main():
             "config": {"workload": "cfg2: 128x256 piano-roll, batch=64 per GPU, full G+D+emotion-D step "
                                    "(1 critic update incl. gradient penalty + 1 generator update)",
                        "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
-                       "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2)},
+                       "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2),
+                       "dp_mode": dp.mode if dp.active else None},
             "event_timing": event_timing, "roofline": roof, "roofline_stride2_family": roof2, "cpu_baseline": cpu,
             "secondary_bf16_ed": sec,
             "secondary": sched,

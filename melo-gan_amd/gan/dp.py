@@ -6,7 +6,22 @@ gradient buffers (critic 1.25 MB every batch; generator + numeric encoder 18.8 M
 steps), the 1/world factor folded into the fused Adam launch (grad_scale).  On ROCm the "nccl"
 backend is RCCL over xGMI.
 
-A batch's step is a fixed sequence of hipGraphs with the collectives between them.  With a generator update:
+Step orders (MELO_DP_MODE).  The default on real GPUs is **ingraph** (round 3): a PRIVATE RCCL communicator (gan/rccl.py,
+ctypes over librccl: `ncclAllReduce` / `ncclAllGather` take the engine's stream and are captured like kernel launches), so
+the N > 1 step is exactly the N = 1 step -- one graph per batch, or the split flow's four with the emotion branch on the side
+stream -- with three collective nodes inside it:
+
+    C1  group{ all-reduce(critic gradient, 1.25 MB), all-gather(a_p0: pre.2's INPUT factor, 128 KB per rank) }   in front of the
+        critic's Adam launch (a_p0 exists since the generator pass: it rides in the collective that is issued anyway)
+    C2  all-gather(d_p2: pre.2's OUTPUT-gradient factor, 2 MB per rank)     in front of the weight-gradient launches, which
+        compute pre.2's GLOBAL weight gradient from the gathered factors (never all-reduced: 16.8 of the 18.8 MB)
+    C3  all-reduce(everything else of the generator / encoder gradient, 2 MB)    in front of the generator's Adam launch
+
+No host involvement between the pieces, no process-group watchdog (torch.distributed only broadcasts the parameters at
+start-up), nothing to prepare() before the first collective.  The older orders below stay for backends without such a
+communicator (gloo: the CPU tests, several ranks rehearsing on one GPU) and as the reference the new one is tested against.
+
+The older orders: a batch's step is a fixed sequence of hipGraphs with the collectives between them.  With a generator update:
 
     G1  dg_forward_d_backward_rng   one Philox draw, the 2B-row E_num + generator pass, the critic step's forward/backward
     C1  all-reduce(critic gradient, 1.25 MB)
@@ -57,25 +72,77 @@ from __future__ import annotations
 
 import os
 
-MODES = ("auto", "overlap", "gather", "allreduce")
+MODES = ("auto", "ingraph", "overlap", "gather", "allreduce")
+
+
+class InGraphCollectives:
+    """The three collectives of a step, issued from INSIDE the engine's sub-steps (GanEngine.d_update / g_backward_b /
+    g_update call these through `engine.coll`) on the engine's stream -- part of whatever graph the sub-step is captured
+    into.  comm: gan/rccl.py::RcclComm (or TorchDistComm: eager only)."""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def reduce_d(self, e, with_a_p0: bool):
+        """C1: the critic's gradient summed over the ranks; on a generator step pre.2's input factor rides along."""
+        c = self.comm
+        c.group_start()
+        c.all_reduce(e.D.grad)
+        if with_a_p0:
+            c.all_gather(e.a_p0, e.a_p0_all)
+        c.group_end()
+
+    def gather_p2(self, e, with_a_p0: bool):
+        """C2: pre.2's output-gradient factor of every rank (and the input factor if C1 did not carry it)."""
+        c = self.comm
+        c.group_start()
+        c.all_gather(e.d_p2, e.d_p2_all)
+        if with_a_p0:
+            c.all_gather(e.a_p0, e.a_p0_all)
+        c.group_end()
+
+    def reduce_g(self, e):
+        """C3: the generator / encoder gradient except what the gathered factors already gave globally."""
+        if getattr(e, "p2_world", 0):
+            off, n = e.p2_grad_slice()
+            if off != 0:
+                raise RuntimeError("the factor gather expects decoder.pre.2 at offset 0 of the flat gradient")
+            self.comm.all_reduce(e.GE.grad[n:])
+        else:
+            self.comm.all_reduce(e.GE.grad)
 
 
 class DataParallel:
-    def __init__(self, engine, world_size: int, dist=None, group=None, force_collectives: bool = False):
+    def __init__(self, engine, world_size: int, dist=None, group=None, force_collectives: bool = False, comm=None):
         """force_collectives: issue the collectives (and take the N > 1 step order) even at world_size 1 -- a
-        rehearsal of the N > 1 control path on a single-GPU box."""
+        rehearsal of the N > 1 control path on a single-GPU box.  comm: a ready communicator for the ingraph order (tests);
+        by default a private RCCL communicator is created over `dist`'s ranks when its backend is nccl."""
         self.engine, self.world, self.dist, self.group = engine, int(world_size), dist, group
-        self.active = dist is not None and (self.world > 1 or force_collectives)
+        self.active = (dist is not None or comm is not None) and (self.world > 1 or force_collectives)
         self._dry = os.environ.get("MELO_DP_DRY") == "1"      # rehearsal: the N > 1 step order without the collectives
         self.mode = os.environ.get("MELO_DP_MODE", "auto")
         if self.mode not in MODES:
             raise ValueError(f"MELO_DP_MODE={self.mode}: expected one of {MODES}")
-        if self.mode == "auto":
+        self.comm = None
+        can_ingraph = hasattr(engine, "coll") and hasattr(engine, "enable_p2_gather")
+        if self.active and can_ingraph and self.mode in ("auto", "ingraph"):
+            if comm is not None:
+                self.comm = comm
+            elif dist is not None and self._backend() == "nccl":
+                from .rccl import RcclComm
+                self.comm = RcclComm.from_process_group(dist, group)
+            elif self.mode == "ingraph":
+                raise ValueError("MELO_DP_MODE=ingraph needs the nccl (RCCL) backend or an explicit communicator")
+        if self.comm is not None:
+            self.mode = "ingraph"
+        elif self.mode in ("auto", "ingraph"):
             self.mode = "overlap" if self.world >= 8 else "gather"
         if self.mode != "allreduce" and not hasattr(engine, "enable_p2_gather"):
             self.mode = "allreduce"
         if self.active and self.mode != "allreduce":
             engine.enable_p2_gather(self.world)
+        if self.mode == "ingraph":
+            engine.coll = InGraphCollectives(self.comm)
         engine.world_size = self.world
         self._pending = []
         self._prepared = False
@@ -91,6 +158,12 @@ class DataParallel:
         # the one graph instead (0.770)
         self._ed_flow = os.environ.get("MELO_ED_FLOW") or ("split" if getattr(engine, "ed_dtype", "fp32") == "fp32" else "ingraph")
 
+    def _backend(self):
+        try:
+            return self.dist.get_backend(self.group)
+        except Exception:  # noqa: BLE001  (stand-ins without a backend notion)
+            return None
+
     def _flat_state(self):
         e = self.engine
         bufs = [e.D.data, e.GE.data]
@@ -102,7 +175,7 @@ class DataParallel:
 
     def broadcast_params(self, src: int = 0):
         """Once at start: every replica gets rank `src`'s parameters and buffers."""
-        if not self.active:
+        if not self.active or self.dist is None:
             return
         bufs = self._flat_state()
         for t in bufs:
@@ -122,8 +195,8 @@ class DataParallel:
         before the first step().  A no-op for engines without graphs (the CPU stand-ins of the tests) or use_graph=False."""
         e = self.engine
         self._prepared = True
-        if not self.active or not use_graph or not hasattr(e, "_capture"):
-            return
+        if not self.active or not use_graph or not hasattr(e, "_capture") or self.mode == "ingraph":
+            return                          # ingraph: the collectives are graph nodes, nothing to capture ahead of them
         import torch
         keep = [e.D.data, e.D.grad, e.D.m, e.D.v, e.D.state, e.GE.data, e.GE.grad, e.GE.m, e.GE.v, e.GE.state, e.rng_step]
         keep += list(e.Gbuf.values())
@@ -196,7 +269,8 @@ class DataParallel:
         other.  world > 1: the step order of MELO_DP_MODE (module
         docstring)."""
         e = self.engine
-        if not self.active:
+        if not self.active or self.mode == "ingraph":
+            # one GPU -- or N GPUs with the collectives inside the graphs (engine.coll): the same flows
             side = getattr(e, "ed_side", None)
             back_to_back, self._prev_g = self._prev_g and g_step, g_step
             if back_to_back and use_graph and side is not None and self._ed_flow == "split":

@@ -325,6 +325,9 @@ class GanEngine:
                            all(ops.conv16_supported(nb, 4 * self.red, 64, C, True, 8 * self.red) for nb in (B, 2 * B)) and
                            os.environ.get("MELO_MIX_FUSED", "1") == "1")
         self._init_chains()
+        # data parallelism with the collectives INSIDE the sub-steps (DataParallel, mode "ingraph"): an InGraphCollectives
+        self.coll = None
+        self._p2_pending = self._a_p0_gathered = False
         self.world_size = 1
         self.p2_world = 0          # > 0: decoder.pre.2's weight gradient comes from all-gathered factors (enable_p2_gather)
         self.capture_locked = False   # DataParallel.prepare(): every graph is captured before the first collective
@@ -872,6 +875,7 @@ class GanEngine:
         same weights (train_gan.py:186-189 and :216-219 -- the generator is not updated in between), each half has its own
         noise, dropout masks and BatchNorm batch statistics, and the running statistics move twice, critic-step half first."""
         self._require_fold()
+        self._p2_pending, self._a_p0_gathered = bool(self.coll is not None and self.p2_world), False
         self._e_fwd(True, "both", gin=True)
         self._g_fwd(self.X0[2 * self.B:], True, "both")
 
@@ -964,6 +968,9 @@ class GanEngine:
         fp.ticked = False
 
     def d_update(self):
+        if self.coll is not None:           # C1 (gan/dp.py): the critic's gradient; a pending generator step's a_p0 rides along
+            self.coll.reduce_d(self, self._p2_pending and not self._a_p0_gathered)
+            self._a_p0_gathered = self._p2_pending
         self._adam(self.D, self.lr_d)
 
     # -------------------------------------------------------------------------------------
@@ -977,6 +984,7 @@ class GanEngine:
         """E_num + generator forward of the G-step: independent of the critic, so under data parallelism it runs while
         the critic's gradient all-reduce is in flight (DataParallel.step)."""
         self._require_fold()
+        self._p2_pending, self._a_p0_gathered = bool(self.coll is not None and self.p2_world), False
         self._e_fwd(True, "g", gin=True)
         self._g_fwd(self.notes, True, "g")
 
@@ -1119,6 +1127,10 @@ class GanEngine:
         # Linear layers, 12 launches at the launch floor before.
         dn = self.dn_dense if self.dn_dense is not None else self.dnotes
         jobs = list(extra_jobs)
+        if self.coll is not None and self.p2_world:         # C2: pre.2's factors of every rank -> its GLOBAL weight gradient
+            self.coll.gather_p2(self, not self._a_p0_gathered)
+            jobs.append(ops.linear_wgrad(self.a_p0_all, self.d_p2_all, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
+                                         defer=True))
         if not self.p2_world:
             jobs.append(ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
                                          defer=True))
@@ -1180,6 +1192,9 @@ class GanEngine:
         ops.linear_wgrad(self.a_p0_all, self.d_p2_all, self.GE.g["G.decoder.pre.2.weight"], db=self.GE.g["G.decoder.pre.2.bias"])
 
     def g_update(self):
+        if self.coll is not None:
+            self.coll.reduce_g(self)        # C3
+            self._p2_pending = self._a_p0_gathered = False
         self._adam(self.GE, self.lr_g)
 
     # -------------------------------------------------------------------------------------

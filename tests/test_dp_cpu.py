@@ -103,6 +103,54 @@ def _worker(rank, port, out):
             dp.step(True, g_step=False)
             assert log == ["d_backward_rng", "d_update"], (mode, log)
     os.environ.pop("MELO_DP_MODE")
+
+    # ---- the ingraph order (round 3): the collectives are issued from INSIDE the engine's sub-steps through engine.coll, so
+    # the step is the single-GPU flow (one sub-step per batch).  Here over gloo with the torch.distributed adapter; on GPUs
+    # the same calls go to a private RCCL communicator and are captured into the step's graphs (tests/test_dp_gpu.py). ----
+    from melo_gan_amd.gan.rccl import TorchDistComm
+    e2 = types.SimpleNamespace(D=types.SimpleNamespace(grad=fd.clone(), data=params.clone()),
+                               GE=types.SimpleNamespace(grad=fg.clone(), data=params.clone() + 1), world_size=1, coll=None,
+                               p2_world=0, p2_grad_slice=lambda: (0, NBIG))
+    e2.d_p2, e2.a_p0 = torch.full((3, 4), float(rank + 1)), torch.full((3, 2), float(10 * (rank + 1)))
+
+    def enable2(world):
+        e2.p2_world = world
+        e2.d_p2_all, e2.a_p0_all = torch.zeros(world * 3, 4), torch.zeros(world * 3, 2)
+    e2.enable_p2_gather = enable2
+    want = torch.cat([torch.full((3, 4), float(r + 1)) for r in range(WORLD)])
+    seen = []
+
+    def run2(name, use_graph):
+        seen.append(name)
+        e2.D.grad.copy_(fd)
+        if name == "d_step_rng":
+            e2.coll.reduce_d(e2, False)
+            assert torch.equal(e2.D.grad, d_sum)
+            return
+        assert name == "dg_step_rng"
+        e2.a_p0_all.zero_(); e2.d_p2_all.zero_()
+        e2.coll.reduce_d(e2, True)                       # C1: the critic's gradient + pre.2's input factor
+        assert torch.equal(e2.D.grad, d_sum) and torch.equal(e2.a_p0_all[:, 0], 10 * want[:, 0])
+        e2.coll.gather_p2(e2, False)                     # C2
+        assert torch.equal(e2.d_p2_all, want)
+        e2.GE.grad.copy_(fg)
+        e2.GE.grad[:NBIG].copy_(g_sum[:NBIG])            # pre.2's global gradient, computed from the gathered factors
+        e2.coll.reduce_g(e2)                             # C3: the rest
+        assert torch.equal(e2.GE.grad, g_sum)
+    e2.run = run2
+    dp2 = DataParallel(e2, WORLD, dist, comm=TorchDistComm(dist))
+    assert dp2.mode == "ingraph" and dp2.active and e2.coll is not None and e2.p2_world == WORLD and e2.world_size == WORLD
+    dp2.prepare(True)                                    # nothing to prepare: no capture-ahead constraint
+    dp2.step(True, g_step=True)
+    dp2.step(True, g_step=False)
+    assert seen == ["dg_step_rng", "d_step_rng"], seen
+    os.environ["MELO_DP_MODE"] = "ingraph"               # asked for explicitly but no communicator can exist over gloo
+    try:
+        DataParallel(e2, WORLD, dist)
+        raise AssertionError("ingraph without a communicator must be refused")
+    except ValueError:
+        pass
+    os.environ.pop("MELO_DP_MODE")
     dist.destroy_process_group()
 
 

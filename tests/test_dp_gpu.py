@@ -78,7 +78,7 @@ def test_two_rank_trainer_gather_equals_allreduce(tmp_path):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode", ["gather", "allreduce", "overlap"])
+@pytest.mark.parametrize("mode", ["ingraph", "gather", "allreduce", "overlap"])
 def test_step_orders_run_on_a_one_rank_rccl_group(mode):
     """bench.py with MELO_FORCE_DP=1: a 1-rank RCCL ("nccl") process group and the N > 1 step order on this GPU, through
     warm-up, graph capture and replay.  Guards the interplay of on-stream collectives, the process group's watchdog
@@ -93,9 +93,61 @@ def test_step_orders_run_on_a_one_rank_rccl_group(mode):
                         "--profile-steps", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=560)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["dp_mode"] == mode
     for v in line["losses"].values():
         assert v == v and abs(v) < 1e6
+
+
+def test_rccl_collectives_are_graph_nodes_and_the_ingraph_step_equals_the_single_gpu_step():
+    """gan/rccl.py on a 1-rank communicator: all-reduce / all-gather (also grouped) enqueued on the engine's stream, eagerly
+    and replayed from a captured hipGraph; and the data-parallel step with the collectives INSIDE its graphs leaves the same
+    bits as the plain single-GPU step (world = 1: the collectives are identities, grad_scale is 1)."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd import ops
+    from melo_gan_amd.gan import rccl
+    from melo_gan_amd.gan.dp import DataParallel
+    from melo_gan_amd.gan.engine import GanEngine
+    comm = rccl.RcclComm(0, 1, rccl.unique_id())
+    st = torch.cuda.Stream()
+    a, b = torch.arange(1000, dtype=torch.float32, device="cuda"), torch.ones(64, 8, device="cuda")
+    g1, g2 = torch.zeros(64, 8, device="cuda"), torch.zeros(1000, device="cuda")
+    with torch.cuda.stream(st):
+        for graph in (False, True):
+            if graph:
+                torch.cuda.synchronize()
+                g = ops.Graph()
+                g.begin()
+            comm.group_start()
+            comm.all_reduce(a)
+            comm.all_gather(b, g1)
+            comm.group_end()
+            comm.all_gather(a, g2)
+            if graph:
+                g.end()
+                b.fill_(3.0)
+                g.launch()
+            torch.cuda.synchronize()
+            assert torch.equal(a, torch.arange(1000, dtype=torch.float32, device="cuda")) and torch.equal(g1, b) and torch.equal(g2, a)
+    B, T, C = 4, 64, 128
+    cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
+    S = O.build_gan_state(cfg, ed_cfg, "closed_form", d_scale=6.0)
+    batch = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 70)
+    res = []
+    for dp_on in (False, True):
+        e = GanEngine(cfg, ed_cfg, "cuda", B)
+        e.load_state(S.PE, S.PG, S.BG, S.PD, S.PED, S.BED)
+        e.seed(5)
+        dp = DataParallel(e, 1, None, force_collectives=dp_on, comm=comm if dp_on else None)
+        assert dp.mode == ("ingraph" if dp_on else dp.mode) and (e.coll is not None) == dp_on
+        with torch.cuda.stream(e.stream):
+            e.set_batch(*(t.cuda() for t in batch))
+            for g_step in (True, True, True, False, True, True, False, True, True, True):
+                dp.step(True, g_step=g_step)
+            torch.cuda.synchronize()
+        res.append((e.D.data.clone(), e.GE.data.clone(), e.GE.m.clone(), float(e.loss_d_out[0]), float(e.adv), float(e.emo)))
+    for x, y in zip(*res):
+        assert (torch.equal(x, y) if isinstance(x, torch.Tensor) else x == y)
+    comm.destroy()
 
 
 class _Work:
@@ -150,7 +202,26 @@ class _ThreadDist:
         return _Work()
 
 
-@pytest.mark.parametrize("mode", ["overlap", "gather", "allreduce"])
+class _ThreadComm:
+    """gan/rccl.py's communicator interface over _ThreadDist (eager only): the ingraph step order on two threads."""
+
+    def __init__(self, td):
+        self.td, self.rank, self.world = td, td.rank, td.world
+
+    def all_reduce(self, t):
+        self.td.all_reduce(t)
+
+    def all_gather(self, src, dst):
+        self.td.all_gather_into_tensor(dst, src)
+
+    def group_start(self):
+        pass
+
+    def group_end(self):
+        pass
+
+
+@pytest.mark.parametrize("mode", ["ingraph", "overlap", "gather", "allreduce"])
 def test_two_engines_as_two_ranks_full_step(mode, monkeypatch):
     """DataParallel.step for the full critic + generator step with two engines as two ranks (two threads, a barrier-based
     stand-in for torch.distributed): graphs captured by prepare(), every collective of the mode's step order issued.
@@ -174,10 +245,11 @@ def test_two_engines_as_two_ranks_full_step(mode, monkeypatch):
         shard = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 70 + r)
         with torch.cuda.stream(e.stream):
             e.set_batch(*(t.cuda() for t in shard))
-            dp = DataParallel(e, WORLD, _ThreadDist(r, WORLD, barrier, slots), force_collectives=False)
+            td = _ThreadDist(r, WORLD, barrier, slots)
+            dp = DataParallel(e, WORLD, td, force_collectives=False, comm=_ThreadComm(td) if mode == "ingraph" else None)
             assert dp.active and dp.mode == mode
             dp.prepare(True)                 # dry steps: no rendezvous, so the ranks can be prepared one after the other
-        assert e.capture_locked and int(e.rng_step.item()) == 0 and float(e.D.state[0].item()) == 0.0
+        assert (e.capture_locked or mode == "ingraph") and int(e.rng_step.item()) == 0 and float(e.D.state[0].item()) == 0.0
         engs.append(e); dps.append(dp); shards.append(shard)
     for k in S.PD:
         assert torch.equal(engs[0].D.p[k].cpu(), S.PD[k]) and torch.equal(engs[1].D.p[k].cpu(), S.PD[k])   # prepare() restored
@@ -187,7 +259,9 @@ def test_two_engines_as_two_ranks_full_step(mode, monkeypatch):
         try:
             with torch.cuda.stream(engs[r].stream):
                 dps[r].broadcast_params()
-                dps[r].step(True, g_step=True)
+                # ingraph over the thread stand-in: eager (a Python rendezvous cannot be a graph node); RCCL's are captured
+                # in test_rccl_collectives_are_graph_nodes_and_the_ingraph_step_equals_the_single_gpu_step
+                dps[r].step(mode != "ingraph", g_step=True)
                 torch.cuda.current_stream().synchronize()
         except Exception as ex:                  # noqa: BLE001
             errors.append(ex)
