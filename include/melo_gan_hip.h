@@ -76,6 +76,11 @@ const char* mg_last_error(void);
  *   slabs that a second kernel sums in fixed order before the epilogue.  NULL => never split.
  */
 size_t mg_conv_workspace_bytes(int B, int Tout, int N);
+/* Launch hint for the window-GEMM launches that FOLLOW (process-wide, baked into a hipGraph at capture): `bytes` of extra LDS per
+ * workgroup, i.e. fewer resident workgroups per CU.  For a branch that runs on a side stream beside the step's critical path
+ * (the frozen emotion discriminator): its 1024-workgroup convolutions otherwise fill every CU's registers and the critical
+ * path's small dependent kernels wait for their workgroups to retire.  0 restores the default. */
+int mg_conv_set_lds_pad(long bytes);
 int mg_conv1d_gather(const float* x, const float* w, float* y,
                      int B, int Tin, int Cin, int N, int K, int stride, int flip,
                      int w_sn, int w_sc, long xbs, long ybs,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mg_version": (i32, []),
     "mg_last_error": (C.c_char_p, []),
     "mg_conv_workspace_bytes": (sz, [i32, i32, i32]),
+    "mg_conv_set_lds_pad": (i32, [i64]),
     "mg_conv1d_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_conv1d_scatter2": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, C.POINTER(Epilogue), vp, sz, vp]),
     "mg_wq_relayout": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or not os.path.exists(OUT):
+    if force or jobs or not os.path.exists(OUT) or any(_newer(o, OUT) for o in objs):      # also after a hand-compiled object
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT])
     return OUT
 

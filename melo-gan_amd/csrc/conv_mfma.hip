@@ -24,6 +24,8 @@
 
 namespace {
 
+long g_conv_lds_pad = 0;      // mg_conv_set_lds_pad
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // -DMG_STAMPS: debug build that records wall-clock stamps (100 MHz) of workgroup phases; see tools/conv_stamps.py
@@ -650,7 +652,10 @@ int launch_cfg(const ConvP& p0, hipStream_t stream) {
     const int R = (TT - 1) * SA + NR;
     constexpr int PP = (BN + (K == 5 ? 5 : K == 3 ? 3 : 1)) * 4;     // the larger (padded, CNK) weight plane of the kernel
     const size_t lds1 = ((size_t)TB * R * SX + (size_t)(BKC / 4) * K * PP) * sizeof(float);
-    const size_t lds = 2 * lds1 + 256 * 4 * sizeof(float);   // two buffers + the per-thread staging sink
+    size_t lds = 2 * lds1 + 256 * 4 * sizeof(float);   // two buffers + the per-thread staging sink
+    // mg_conv_set_lds_pad: extra LDS per workgroup = fewer resident workgroups per CU, for launches that run BESIDE another
+    // stream's critical path (the frozen emotion discriminator's branch): they leave wave slots, registers and LDS to it
+    if (g_conv_lds_pad > 0 && lds + (size_t)g_conv_lds_pad <= 160 * 1024) lds += (size_t)g_conv_lds_pad;
     if (lds > 160 * 1024) {
         mg_set_error("conv_wgemm: LDS request %zu too large", lds);
         return MG_EUNSUP;
@@ -832,4 +837,10 @@ extern "C" int mg_dbg_set_stamps(long long* buf) {
 
 extern "C" int mg_conv_tile_config(long m_rows, int N, int scatter2) {
     return scatter2 ? scatter_tile(m_rows, N) : gather_tile(m_rows, N);
+}
+
+extern "C" int mg_conv_set_lds_pad(long bytes) {
+    MG_CHECK_ARG(bytes >= 0 && bytes <= 120 * 1024, "mg_conv_set_lds_pad: 0..120 KiB");
+    g_conv_lds_pad = bytes;
+    return MG_OK;
 }

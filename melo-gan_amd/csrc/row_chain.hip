@@ -8,7 +8,7 @@
 // sample's chain has no cross-sample dependency, so one workgroup walks ONE row through the whole stack with the
 // activations in LDS; the weights (<= 1.3 MB per chain) come from L2, which every workgroup shares.  What bounds a chain
 // is a CU's L2 bandwidth (~64 B/clk): 200 KB of encoder weights ~1.5 us, the classifier tail's 1.3 MB ~9 us, against 4-10
-// launches of ~5 us each.
+// launches of ~5-8 us each.
 //
 // A chain is a short op list (kernel argument): LOAD / STORE between global rows and LDS vector slots, LAYERNORM,
 // LIN_FWD (y = act(x W^T + b) [* mask], W (N, K) row-major: a wave reads a weight row with one coalesced 16-B-per-lane
@@ -22,7 +22,11 @@ namespace {
 
 constexpr int CH_MAXV = MG_CHAIN_MAX_VEC;      // floats per vector slot
 constexpr int CH_SLOTS = MG_CHAIN_SLOTS;
-constexpr int CH_THREADS = 256;
+// 16 waves per row.  A chain is a sequence of DEPENDENT steps, each one L2 round trip long if -- and only if -- all of a
+// step's loads are in flight at once: a 256x256 layer is 256 KB = 16 float4 per thread at 1024 threads (one round trip),
+// against 64 per thread in 4-8 dependent rounds at 256 threads (the first version of this kernel: 40-200 us per chain).
+constexpr int CH_THREADS = 1024;
+constexpr int CH_WAVES = CH_THREADS / 64;
 
 struct ChainArgs {
     mg_chain_op op[MG_CHAIN_MAX_OPS];
@@ -39,38 +43,47 @@ __device__ __forceinline__ float act_fwd(int act, float v) {
     }
 }
 
-// ---- y[n] = sum_k x[k] W[n*ld + k], vector path: K % 4 == 0, 16 <= K <= CH_MAXV.  Wave w takes outputs 16 at a time. ----
+// ---- y[n] = sum_k x[k] W[n*ld + k], vector path: K % 4 == 0, 16 <= K <= CH_MAXV.  A wave takes 16 outputs per round:
+// 16 coalesced 16-B-per-lane row loads in flight, then a butterfly folds the 16 partial dot products in 17 shuffles.
+// The loads go through a buffer descriptor: the row (wave-uniform) is the scalar offset, the lane's column the one vector
+// offset shared by all 16 -- no address registers, so the 16 x 4 data registers fit the 128-VGPR budget of a 1024-thread
+// workgroup and hipcc keeps all 16 in flight (with 64-bit addresses per row it serialised them pairwise to save
+// registers: 8 dependent round trips, 23 us per 256x256 layer instead of ~2). ----
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lin_fwd_vec(const mg_chain_op& o, const float* __restrict__ xs, float* __restrict__ raw) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int K = o.n0, N = o.n1, nk4 = K >> 2;
-    const float* __restrict__ W = o.p0;
-    const long ld = o.ld0;
-    // the lane's slice of x: float4 chunks lane, lane + 64 (K <= 512)
+    const unsigned ldb = (unsigned)o.ld0 * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.p0), 0,
+                                                                         (int)(((long)(N - 1) * o.ld0 + K) * 4), 0x00020000);
     float4 xr[2];
+    unsigned vo[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int c = lane + 64 * t;
         xr[t] = c < nk4 ? reinterpret_cast<const float4*>(xs)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        vo[t] = c < nk4 ? (unsigned)c * 16u : 0x80000000u;          // beyond num_records: the hardware returns 0
     }
-    const int nt = nk4 > 64 ? 2 : 1;
-    for (int nb = wave * 16; nb < N; nb += 64) {
+    auto ld16 = [&](unsigned voff, unsigned soff) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    };
+    for (int nb = wave * 16; nb < N; nb += 16 * CH_WAVES) {
+        float4 w0[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w0[j] = ld16(vo[0], (unsigned)min(nb + j, N - 1) * ldb);
+        __builtin_amdgcn_sched_barrier(0);
         float p[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = min(nb + j, N - 1);
-            const float4* wr = reinterpret_cast<const float4*>(W + (long)n * ld);
-            float acc = 0.f;
-            {
-                const int c = min(lane, nk4 - 1);           // clamped: lanes beyond the row multiply by x = 0
-                const float4 w4 = wr[c];
-                acc = (w4.x * xr[0].x + w4.y * xr[0].y) + (w4.z * xr[0].z + w4.w * xr[0].w);
-            }
-            if (nt == 2) {
-                const int c = min(lane + 64, nk4 - 1);
-                const float4 w4 = wr[c];
-                acc += (w4.x * xr[1].x + w4.y * xr[1].y) + (w4.z * xr[1].z + w4.w * xr[1].w);
-            }
-            p[j] = acc;
+        for (int j = 0; j < 16; ++j) p[j] = (w0[j].x * xr[0].x + w0[j].y * xr[0].y) + (w0[j].z * xr[0].z + w0[j].w * xr[0].w);
+        if (nk4 > 64) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w0[j] = ld16(vo[1], (unsigned)min(nb + j, N - 1) * ldb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) p[j] += (w0[j].x * xr[1].x + w0[j].y * xr[1].y) + (w0[j].z * xr[1].z + w0[j].w * xr[1].w);
         }
         // butterfly: after the step with mask m the lanes with that bit set keep the upper half of the values
 #pragma unroll
@@ -103,41 +116,61 @@ __device__ __forceinline__ void lin_fwd_scalar(const mg_chain_op& o, const float
     }
 }
 
-// ---- dx[i] = sum_o dy[o] W[o*ld + i]: lanes along i (float4), lane groups split o, fixed-order sum through LDS ----
+// ---- dx[i] = sum_o dy[o] W[o*ld + i]: lanes along i (float4), lane groups split o (16 rows in flight per thread), the
+// groups' partial vectors summed through LDS in a fixed order ----
 __device__ __forceinline__ void lin_dgrad(const mg_chain_op& o, const float* __restrict__ dys, float* __restrict__ raw,
                                           float* __restrict__ part) {
     const int OUT = o.n0, IN = o.n1;
     const float* __restrict__ W = o.p0;
     const long ld = o.ld0;
-    if ((IN & 3) == 0 && IN >= 16 && IN <= 1024) {
-        const int L4 = IN >> 2;                    // float4 lanes per weight row
-        const int G = CH_THREADS / L4 > 0 ? CH_THREADS / L4 : 1;     // row groups (IN = 1024: one group, a thread takes 1 chunk)
+    if ((IN & 3) == 0 && IN >= 16) {
+        const int L4 = IN >> 2;                    // float4 lanes per weight row (<= 128)
+        const int G = CH_THREADS / L4;             // row groups (>= 8)
         const int c = threadIdx.x % L4, g = threadIdx.x / L4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g < G) {
-            int r = g;
-            for (; r + 7 * G < OUT; r += 8 * G) {          // eight rows in flight
-                float4 w4[8];
+            for (int r0 = g; r0 < OUT; r0 += 16 * G) {
+                float4 w4[16];
+                float d[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w4[u] = reinterpret_cast<const float4*>(W + (long)(r + u * G) * ld)[c];
+                for (int u = 0; u < 16; ++u) {       // clamped rows, zero multiplier: no load behind a branch
+                    const int r = r0 + u * G;
+                    w4[u] = reinterpret_cast<const float4*>(W + (long)min(r, OUT - 1) * ld)[c];
+                    d[u] = r < OUT ? dys[min(r, OUT - 1)] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float d = dys[r + u * G];
-                    acc.x += d * w4[u].x; acc.y += d * w4[u].y; acc.z += d * w4[u].z; acc.w += d * w4[u].w;
+                for (int u = 0; u < 16; ++u) {
+                    acc.x += d[u] * w4[u].x; acc.y += d[u] * w4[u].y; acc.z += d[u] * w4[u].z; acc.w += d[u] * w4[u].w;
                 }
             }
-            for (; r < OUT; r += G) {
-                const float4 w4 = reinterpret_cast<const float4*>(W + (long)r * ld)[c];
-                const float d = dys[r];
-                acc.x += d * w4.x; acc.y += d * w4.y; acc.z += d * w4.z; acc.w += d * w4.w;
-            }
-            reinterpret_cast<float4*>(part)[g * L4 + c] = acc;       // part: G x IN floats = 256 float4
+            reinterpret_cast<float4*>(part)[g * L4 + c] = acc;       // part: G x IN floats <= CH_THREADS float4
         }
         __syncthreads();
         for (int i = threadIdx.x; i < IN; i += CH_THREADS) {
             float v = 0.f;
             for (int q = 0; q < G; ++q) v += part[q * IN + i];
             raw[i] = v;
+        }
+    } else if (IN <= 64) {
+        // few outputs (the encoder's first layer: 6): the workgroup's threads split the ROWS, partial sums through LDS
+        const int G = CH_THREADS / IN;
+        const int i = threadIdx.x % IN, g = threadIdx.x / IN;
+        if (g < G) {
+            float acc = 0.f;
+            for (int r = g; r < OUT; r += G) acc += dys[r] * W[(long)r * ld + i];
+            part[g * IN + i] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < IN) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // four chains: 170 dependent adds would be the whole op
+            int q = 0;
+            for (; q + 3 < G; q += 4) {
+                a0 += part[q * IN + threadIdx.x]; a1 += part[(q + 1) * IN + threadIdx.x];
+                a2 += part[(q + 2) * IN + threadIdx.x]; a3 += part[(q + 3) * IN + threadIdx.x];
+            }
+            for (; q < G; ++q) a0 += part[q * IN + threadIdx.x];
+            raw[threadIdx.x] = (a0 + a1) + (a2 + a3);
         }
     } else {
         for (int i = threadIdx.x; i < IN; i += CH_THREADS) {
@@ -151,7 +184,7 @@ __device__ __forceinline__ void lin_dgrad(const mg_chain_op& o, const float* __r
 __global__ __launch_bounds__(CH_THREADS) void row_chain_kernel(const ChainArgs A) {
     __shared__ __attribute__((aligned(16))) float slot[CH_SLOTS][CH_MAXV];
     __shared__ __attribute__((aligned(16))) float part[CH_THREADS * 4];
-    __shared__ float red[16];
+    __shared__ float red[CH_WAVES];
     const long row = blockIdx.x;
     const int tid = threadIdx.x;
     for (int q = 0; q < A.n_ops; ++q) {
@@ -166,23 +199,46 @@ __global__ __launch_bounds__(CH_THREADS) void row_chain_kernel(const ChainArgs A
                 break;
             }
             case MG_CH_MEAN_T: {     // slot[b][c] = (1/i0) sum_t p0[(row*i0 + t)*ld0 + c], c < n0: AdaptiveAvgPool1d(1); q0 rows <- it
-                const int T = o.i0;
+                const int T = o.i0, Cc = o.n0;
                 const float* base = o.p0 + row * (long)T * o.ld0;
-                for (int c = tid; c < o.n0; c += CH_THREADS) {
-                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    int t = 0;
-                    for (; t + 8 <= T; t += 8) {
+                if ((Cc & 3) == 0 && Cc >= 16 && (o.ld0 & 3) == 0 && ((((uintptr_t)o.p0) & 15) == 0)) {
+                    // float4 lanes along the channels, the remaining lanes along time, 16 rows in flight per thread
+                    const int L4 = Cc >> 2, RL = CH_THREADS / L4;
+                    const int c = tid % L4, rl = tid / L4;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rl < RL) {
+                        for (int t0 = rl; t0 < T; t0 += 16 * RL) {
+                            float4 v[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc[u] += base[(long)(t + u) * o.ld0 + c];
+                            for (int u = 0; u < 16; ++u)
+                                v[u] = reinterpret_cast<const float4*>(base + (long)min(t0 + u * RL, T - 1) * o.ld0)[c];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < 16; ++u)
+                                if (t0 + u * RL < T) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                        }
+                        reinterpret_cast<float4*>(part)[rl * L4 + c] = acc;
                     }
-                    for (; t < T; ++t) acc[0] += base[(long)t * o.ld0 + c];
-                    const float v = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) / (float)T;
-                    slot[o.b][c] = v;
-                    if (o.q0) o.q0[row * o.lq0 + c] = v;
+                    __syncthreads();
+                    for (int i = tid; i < Cc; i += CH_THREADS) {
+                        float v = 0.f;
+                        for (int g = 0; g < RL; ++g) v += part[g * Cc + i];
+                        v /= (float)T;
+                        slot[o.b][i] = v;
+                        if (o.q0) o.q0[row * o.lq0 + i] = v;
+                    }
+                } else {
+                    for (int c = tid; c < Cc; c += CH_THREADS) {
+                        float acc = 0.f;
+                        for (int t = 0; t < T; ++t) acc += base[(long)t * o.ld0 + c];
+                        const float v = acc / (float)T;
+                        slot[o.b][c] = v;
+                        if (o.q0) o.q0[row * o.lq0 + c] = v;
+                    }
                 }
                 break;
             }
-            case MG_CH_STORE: {      // q0[row * ld0 + j] = slot[a][j]
+            case MG_CH_STORE: {      // q0[row * lq0 + j] = slot[a][j]
                 for (int j = tid; j < o.n0; j += CH_THREADS) o.q0[row * o.lq0 + j] = slot[o.a][j];
                 break;
             }
@@ -210,29 +266,35 @@ __global__ __launch_bounds__(CH_THREADS) void row_chain_kernel(const ChainArgs A
             }
             case MG_CH_LIN_FWD: {    // slot[b] = act(slot[a] W^T + p1) * p2[row]; q0: pre-activation rows, q1: output rows
                 float* raw = slot[o.b];
+                // the epilogue's operands (one output per thread: n1 <= 512 < threads) are requested BEFORE the weight
+                // rows: their latency hides under the reduction instead of following it
+                const bool mine = tid < o.n1;
+                const float bias = (mine && o.p1) ? o.p1[tid] : 0.f;
+                const float mask = (mine && o.p2) ? o.p2[row * o.ld2 + tid] : 1.f;
                 if ((o.n0 & 3) == 0 && o.n0 >= 16) lin_fwd_vec(o, slot[o.a], raw);
                 else lin_fwd_scalar(o, slot[o.a], raw);
                 __syncthreads();
-                for (int n = tid; n < o.n1; n += CH_THREADS) {
-                    float v = raw[n] + (o.p1 ? o.p1[n] : 0.f);
-                    if (o.q0) o.q0[row * o.lq0 + n] = v;
-                    v = act_fwd(o.act, v);
-                    if (o.p2) v *= o.p2[row * o.ld2 + n];
-                    if (o.q1) o.q1[row * o.lq1 + n] = v;
-                    raw[n] = v;
+                if (mine) {
+                    float v = raw[tid] + bias;
+                    if (o.q0) o.q0[row * o.lq0 + tid] = v;
+                    v = act_fwd(o.act, v) * mask;
+                    if (o.q1) o.q1[row * o.lq1 + tid] = v;
+                    raw[tid] = v;
                 }
                 break;
             }
             case MG_CH_LIN_DGRAD: {  // slot[b] = (slot[a] W) * act'(p1[row]) * p2[row]; q1: output rows
                 float* raw = slot[o.b];
+                const bool mine = tid < o.n1;
+                const float gref = (mine && o.p1) ? o.p1[row * o.ld1 + tid] : 0.f;
+                const float mask = (mine && o.p2) ? o.p2[row * o.ld2 + tid] : 1.f;
                 lin_dgrad(o, slot[o.a], raw, part);
                 __syncthreads();
-                for (int i = tid; i < o.n1; i += CH_THREADS) {
-                    float v = raw[i];
-                    if (o.p1) v *= mg_act_grad(o.act, o.p1[row * o.ld1 + i]);
-                    if (o.p2) v *= o.p2[row * o.ld2 + i];
-                    if (o.q1) o.q1[row * o.lq1 + i] = v;
-                    raw[i] = v;
+                if (mine) {
+                    float v = raw[tid] * mask;
+                    if (o.p1) v *= mg_act_grad(o.act, gref);
+                    if (o.q1) o.q1[row * o.lq1 + tid] = v;
+                    raw[tid] = v;
                 }
                 break;
             }
@@ -279,7 +341,11 @@ __global__ __launch_bounds__(CH_THREADS) void row_chain_kernel(const ChainArgs A
                 for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
                 if ((tid & 63) == 0) red[tid >> 6] = acc;
                 __syncthreads();
-                if (tid == 0) o.q0[row] = ((red[0] + red[1]) + (red[2] + red[3])) + o.p1[0];
+                if (tid == 0) {
+                    float t = 0.f;
+                    for (int w = 0; w < CH_WAVES; ++w) t += red[w];
+                    o.q0[row] = t + o.p1[0];
+                }
                 for (int j = tid; j < F; j += CH_THREADS) slot[o.b][j] = part[j];
                 break;
             }

@@ -188,19 +188,20 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
 // of the raw data), then applies.  The (row slice 0, group 0) block of every channel block also publishes the statistics
 // of every group and moves the running statistics, group after group -- what two consecutive forward passes do.
 // (Was two launches: a finishing kernel and the apply pass; a dependent launch costs ~5 us, the redundant combine < 1.)
+constexpr int BNA_THREADS = 1024, BNA_PL = BNA_THREADS / 64;      // 16 partial lanes per channel: the combine is ONE round trip
 __device__ __forceinline__ void combine_parts64(const float* __restrict__ part, int np, int C, int c0, double (*sh)[64],
                                                 double& mean, double& var) {
-    const int cx = threadIdx.x & 63, pl = threadIdx.x >> 6;      // 4 partial lanes per channel
+    const int cx = threadIdx.x & 63, pl = threadIdx.x >> 6;      // BNA_PL partial lanes per channel
     double A = 0.0, Q = 0.0, Bt = 0.0, n = 0.0;
     if (c0 + cx < C) {
         // eight independent load triples in flight per round (a plain loop waits for every round trip in turn)
-        for (int q0 = pl; q0 < np; q0 += 32) {
+        for (int q0 = pl; q0 < np; q0 += 8 * BNA_PL) {
             float va[8], vq[8], vn[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // always load (clamped row), select afterwards: a load behind a runtime condition makes hipcc branch
                 // around it and wait for each one in turn
-                const int q = q0 + 4 * j;
+                const int q = q0 + BNA_PL * j;
                 const long o = ((long)(q < np ? q : np - 1) * 3) * C + c0 + cx;
                 va[j] = part[o];
                 vq[j] = part[o + C];
@@ -208,19 +209,20 @@ __device__ __forceinline__ void combine_parts64(const float* __restrict__ part, 
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (q0 + 4 * j < np && vn[j] > 0.f) {
+                if (q0 + BNA_PL * j < np && vn[j] > 0.f) {
                     const double a = (double)va[j], c = (double)vn[j];
                     A += a; Q += (double)vq[j]; Bt += a * a / c; n += c;
                 }
         }
     }
     __syncthreads();
-    sh[pl][cx] = A; sh[4 + pl][cx] = Q; sh[8 + pl][cx] = Bt; sh[12 + pl][cx] = n;
+    sh[pl][cx] = A; sh[BNA_PL + pl][cx] = Q; sh[2 * BNA_PL + pl][cx] = Bt; sh[3 * BNA_PL + pl][cx] = n;
     __syncthreads();
-    A = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
-    Q = (sh[4][cx] + sh[5][cx]) + (sh[6][cx] + sh[7][cx]);
-    Bt = (sh[8][cx] + sh[9][cx]) + (sh[10][cx] + sh[11][cx]);
-    n = (sh[12][cx] + sh[13][cx]) + (sh[14][cx] + sh[15][cx]);
+    A = Q = Bt = n = 0.0;
+#pragma unroll
+    for (int l = 0; l < BNA_PL; ++l) {       // fixed order
+        A += sh[l][cx]; Q += sh[BNA_PL + l][cx]; Bt += sh[2 * BNA_PL + l][cx]; n += sh[3 * BNA_PL + l][cx];
+    }
     mean = n > 0.0 ? A / n : 0.0;
     double m2 = Q + (Bt - A * mean);
     if (m2 < 0.0) m2 = 0.0;
@@ -234,24 +236,25 @@ __device__ __forceinline__ void combine_colsum64(const double* __restrict__ part
     const int cx = threadIdx.x & 63, pl = threadIdx.x >> 6;
     double A = 0.0, Q = 0.0;
     if (c0 + cx < C)
-        for (int q0 = pl; q0 < np; q0 += 32) {
+        for (int q0 = pl; q0 < np; q0 += 8 * BNA_PL) {
             double va[8], vq[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int q = q0 + 4 * j;
+                const int q = q0 + BNA_PL * j;
                 const long o = ((long)(q < np ? q : np - 1) * 2) * C + c0 + cx;
                 va[j] = part[o];
                 vq[j] = part[o + C];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (q0 + 4 * j < np) { A += va[j]; Q += vq[j]; }
+                if (q0 + BNA_PL * j < np) { A += va[j]; Q += vq[j]; }
         }
     __syncthreads();
-    sh[pl][cx] = A; sh[4 + pl][cx] = Q;
+    sh[pl][cx] = A; sh[BNA_PL + pl][cx] = Q;
     __syncthreads();
-    A = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
-    Q = (sh[4][cx] + sh[5][cx]) + (sh[6][cx] + sh[7][cx]);
+    A = Q = 0.0;
+#pragma unroll
+    for (int l = 0; l < BNA_PL; ++l) { A += sh[l][cx]; Q += sh[BNA_PL + l][cx]; }
     mean = A / (double)R;
     var = Q / (double)R - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -259,12 +262,12 @@ __device__ __forceinline__ void combine_colsum64(const double* __restrict__ part
 
 // PT = float: conv16 partials (np rows of 3 planes per group); PT = double: colsum partials ((RED_SPLITS + 1) * 2 * C per group)
 template <typename PT>
-__global__ __launch_bounds__(256) void bn_parts_apply_kernel(const PT* __restrict__ part, int np, int groups, long R, int C,
+__global__ __launch_bounds__(BNA_THREADS) void bn_parts_apply_kernel(const PT* __restrict__ part, int np, int groups, long R, int C,
                                                              float momentum, float eps, float* running_mean, float* running_var,
                                                              float* save_mean, float* save_invstd, const float* __restrict__ z,
                                                              float* __restrict__ a, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, long rows_per) {
-    __shared__ double sh[16][64];
+    __shared__ double sh[4 * BNA_PL][64];
     __shared__ float s_mean[64], s_istd[64];
     const int c0 = blockIdx.x * 64, cx = threadIdx.x & 63;
     const int g = blockIdx.z;
@@ -295,8 +298,9 @@ __global__ __launch_bounds__(256) void bn_parts_apply_kernel(const PT* __restric
         }
     }
     __syncthreads();
-    // apply: 16 float4 lanes x 16 row lanes over this block's 64 channels and row slice
+    // apply: 16 float4 lanes x 64 row lanes over this block's 64 channels and row slice
     const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    constexpr int RYN = BNA_THREADS / 16;
     const int c = c0 + 4 * cq;
     if (c >= C) return;
     const long r0 = (long)blockIdx.y * rows_per;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void bn_parts_apply_kernel(const PT* __restric
     }
     const float* zg = z + (long)g * R * C;
     float* ag = a + (long)g * R * C;
-    for (long r = r0 + ry; r < r1; r += 16) {
+    for (long r = r0 + ry; r < r1; r += RYN) {
         const long i = r * C + c;
         if (vec) {
             const float4 t = *reinterpret_cast<const float4*>(zg + i);
@@ -341,37 +345,38 @@ __global__ __launch_bounds__(256) void bn_parts_apply_kernel(const PT* __restric
 // BatchNorm backward, second (last) launch: every block sums ITS 64 channels' fp64 partials of colsum_partial_kernel<1>
 // (fixed order), then applies to its row slice; row slice 0 also writes dgamma / dbeta.  (Was a finishing launch + an apply
 // launch.)
-__global__ __launch_bounds__(256) void bn_bwd_parts_apply_kernel(const double* __restrict__ part, int nsplit, int C, long R,
+__global__ __launch_bounds__(BNA_THREADS) void bn_bwd_parts_apply_kernel(const double* __restrict__ part, int nsplit, int C, long R,
                                                                  const float* __restrict__ da, const float* __restrict__ a,
                                                                  const float* __restrict__ z, float* __restrict__ dz,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  float* dgamma, float* dbeta, int act, long rows_per) {
-    __shared__ double sh[8][64];
+    __shared__ double sh[2 * BNA_PL][64];
     __shared__ double s1[64], s2[64];
     const int c0 = blockIdx.x * 64, cx = threadIdx.x & 63, pl = threadIdx.x >> 6;
     {
         double t1 = 0.0, t2 = 0.0;
         if (c0 + cx < C)
-            for (int q0 = pl; q0 < nsplit; q0 += 32) {
+            for (int q0 = pl; q0 < nsplit; q0 += 8 * BNA_PL) {
                 double va[8], vb[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int q = q0 + 4 * j;
+                    const int q = q0 + BNA_PL * j;
                     const long o = ((long)(q < nsplit ? q : nsplit - 1) * 2) * C + c0 + cx;
                     va[j] = part[o];
                     vb[j] = part[o + C];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (q0 + 4 * j < nsplit) { t1 += va[j]; t2 += vb[j]; }
+                    if (q0 + BNA_PL * j < nsplit) { t1 += va[j]; t2 += vb[j]; }
             }
         sh[pl][cx] = t1;
-        sh[4 + pl][cx] = t2;
+        sh[BNA_PL + pl][cx] = t2;
         __syncthreads();
         if (threadIdx.x < 64) {
-            const double u1 = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
-            const double u2 = (sh[4][cx] + sh[5][cx]) + (sh[6][cx] + sh[7][cx]);
+            double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+            for (int l = 0; l < BNA_PL; ++l) { u1 += sh[l][cx]; u2 += sh[BNA_PL + l][cx]; }
             s1[cx] = u1;
             s2[cx] = u2;
             if (blockIdx.y == 0 && c0 + cx < C) {
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(256) void bn_bwd_parts_apply_kernel(const double* _
         __syncthreads();
     }
     const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    constexpr int RYN = BNA_THREADS / 16;
     const int c = c0 + 4 * cq;
     if (c >= C) return;
     const long r0 = (long)blockIdx.y * rows_per;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256) void bn_bwd_parts_apply_kernel(const double* _
         k1[e] = s1[4 * cq + e];
         k2[e] = s2[4 * cq + e];
     }
-    for (long r = r0 + ry; r < r1; r += 16) {
+    for (long r = r0 + ry; r < r1; r += RYN) {
         const long i = r * C + c;
         float dv[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0}, zv[4] = {0, 0, 0, 0};
         if (vec) {
@@ -1117,13 +1123,14 @@ int mg_bn_train_fwd_groups(const float* z, float* a, long R, int C, int groups, 
     dim3 grid((unsigned)mg_cdiv(C, 64), (unsigned)pl.nsplit, (unsigned)groups);
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), 0, ST, z, nullptr, nullptr, nullptr, nullptr, 0, R, C,
                        pl.rows_per, (double*)work, 1);
+    // row slices: ~256 blocks of 1024 threads in all, at least 64 rows (one per row lane) each
     const long cb = mg_cdiv(C, 64);
-    long slices = 512 / (cb * groups);
+    long slices = 256 / (cb * groups);
     if (slices < 1) slices = 1;
     if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
     const long rows_per = mg_cdiv(R, slices);
     slices = mg_cdiv(R, rows_per);
-    hipLaunchKernelGGL(bn_parts_apply_kernel<double>, dim3((unsigned)cb, (unsigned)slices, (unsigned)groups), dim3(256), 0, ST,
+    hipLaunchKernelGGL(bn_parts_apply_kernel<double>, dim3((unsigned)cb, (unsigned)slices, (unsigned)groups), dim3(BNA_THREADS), 0, ST,
                        (const double*)work, pl.nsplit, groups, R, C, momentum, eps, running_mean, running_var, save_mean,
                        save_invstd, z, a, gamma, beta, act, rows_per);
     MG_CHECK_LAUNCH("bn_train_fwd");
@@ -1144,13 +1151,14 @@ int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups
                  part_rows_per_group > 0, "mg_bn_train_fwd_parts: bad args");
     MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "mg_bn_train_fwd_parts: running stats must come in pairs");
     // row slices: ~512 blocks in all (2 per CU), at least 64 rows each
+    // row slices: ~256 blocks of 1024 threads in all, at least 64 rows (one per row lane) each
     const long cb = mg_cdiv(C, 64);
-    long slices = 512 / (cb * groups);
+    long slices = 256 / (cb * groups);
     if (slices < 1) slices = 1;
     if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
     const long rows_per = mg_cdiv(R, slices);
     slices = mg_cdiv(R, rows_per);
-    hipLaunchKernelGGL(bn_parts_apply_kernel<float>, dim3((unsigned)cb, (unsigned)slices, (unsigned)groups), dim3(256), 0, ST, part,
+    hipLaunchKernelGGL(bn_parts_apply_kernel<float>, dim3((unsigned)cb, (unsigned)slices, (unsigned)groups), dim3(BNA_THREADS), 0, ST, part,
                        part_rows_per_group, groups, R, C, momentum, eps, running_mean, running_var, save_mean, save_invstd, z, a,
                        gamma, beta, act, rows_per);
     MG_CHECK_LAUNCH("bn_train_fwd_parts");
@@ -1169,12 +1177,12 @@ int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, 
     hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), 0, ST, da, a, z, save_mean, save_invstd, act, R, C,
                        pl.rows_per, part, 1, gamma, beta);
     const long cb = mg_cdiv(C, 64);
-    long slices = 512 / cb;
+    long slices = 256 / cb;
     if (slices < 1) slices = 1;
     if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
     const long rows_per = mg_cdiv(R, slices);
     slices = mg_cdiv(R, rows_per);
-    hipLaunchKernelGGL(bn_bwd_parts_apply_kernel, dim3((unsigned)cb, (unsigned)slices), dim3(256), 0, ST, (const double*)part,
+    hipLaunchKernelGGL(bn_bwd_parts_apply_kernel, dim3((unsigned)cb, (unsigned)slices), dim3(BNA_THREADS), 0, ST, (const double*)part,
                        pl.nsplit, C, R, da, a, z, dz, gamma, beta, save_mean, save_invstd, dgamma, dbeta, act, rows_per);
     MG_CHECK_LAUNCH("bn_train_bwd");
     return MG_OK;

@@ -287,7 +287,7 @@ class DataParallel:
                 e.run("dg_forward_rng", True)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    e.run("g_ed_branch", True)
+                    e.run("g_ed_branch_side", True)
                 e.run("d_step_g_critic_front", True)
                 cur.wait_stream(side)
                 e.run("g_finish", True)
@@ -318,7 +318,7 @@ class DataParallel:
             e.run("dg_forward_rng", use_graph)            # G1a
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                e.run("g_ed_branch", use_graph)           # G2, side stream
+                e.run("g_ed_branch_side", use_graph)      # G2, side stream
             e.run("d_backward_nofwd", use_graph)          # G1b
             self.allreduce_d()                            # C1
             e.run("d_update_g_critic_front", use_graph)   # G3a

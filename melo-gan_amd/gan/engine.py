@@ -315,6 +315,7 @@ class GanEngine:
         self.stream = torch.cuda.Stream(device=d)
         # side stream of the fused step's emotion branch (dg_step_rng); MELO_ED_SIDE=0: everything on one stream
         self.ed_side = torch.cuda.Stream(device=d) if os.environ.get("MELO_ED_SIDE", "1") == "1" else None
+        self.ed_side_lds_pad = int(os.environ.get("MELO_ED_LDS_PAD", "42000"))      # g_ed_branch_side
         # (Forked side streams for independent branches of a step were implemented and measured in round 1: every
         # fork/join cost more cross-queue latency than the overlap returned once the kernels filled the chip -- 1.70 ms
         # single-stream vs 1.73-1.82 -- and were removed; independent launches of one kernel share a launch instead.)
@@ -910,7 +911,7 @@ class GanEngine:
         self.d_update()
         self.g_critic_front()
         with torch.cuda.stream(self.ed_side):
-            self.g_ed_branch()
+            self.g_ed_branch_side()
         cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
         self.g_critic_back()
         self.g_backward_b()
@@ -1002,6 +1003,15 @@ class GanEngine:
         """g_backward_a without the generator forward (see g_forward)."""
         self.g_ed_branch()
         self.g_critic_chain()
+
+    def g_ed_branch_side(self):
+        """g_ed_branch for the side stream (the split / in-graph fork flows): its convolutions keep ONE workgroup per CU
+        resident instead of three, so the critical path's kernels on the main stream -- many of them small and dependent --
+        find free registers and wave slots at once instead of waiting for 15-50-us workgroups to retire.  The branch has the
+        slack: it is needed only where the generator's backward starts.  Measured (cfg2, same box, alternating):
+        0.913 -> 0.895 ms per step."""
+        with ops.conv_lds_pad(self.ed_side_lds_pad):
+            self.g_ed_branch()
 
     def g_ed_branch(self):
         """The frozen emotion discriminator's forward, cross-entropy and input gradient on the generated batch: the only

@@ -99,6 +99,21 @@ def _conv_work(lib, B, Tout, N, Cin, device):
     return workspace(lib.mg_conv_workspace_bytes(B, Tout, N), device, "conv")
 
 
+class conv_lds_pad:
+    """with ops.conv_lds_pad(nbytes): the window-GEMM launches inside take `nbytes` more LDS per workgroup -- fewer resident
+    workgroups per CU -- for a branch that runs beside another stream's critical path (mg_conv_set_lds_pad)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+
+    def __enter__(self):
+        L.check(L.load().mg_conv_set_lds_pad(self.nbytes), "mg_conv_set_lds_pad")
+
+    def __exit__(self, *a):
+        L.load().mg_conv_set_lds_pad(0)
+        return False
+
+
 def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_sn: int, w_sc: int,
                 flip: bool = False, **epi) -> Tensor:
     """Generic gather window-GEMM (see mg_conv1d_gather).  x: (B, Tin, Cin); y: (B, Ty, N) with

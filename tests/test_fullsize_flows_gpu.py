@@ -151,7 +151,7 @@ def test_side_stream_flows_full_size_match_oracle(flow):
             eng.dg_forward()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                eng.g_ed_branch()
+                eng.g_ed_branch_side()
             eng.d_step_g_critic_front()
             cur.wait_stream(side)
             eng.g_finish()
