@@ -333,10 +333,22 @@ def main():
         pool.append((real, numeric, latent, emot))
     eng.seed(1234 + rank)                            # rank-offset Philox key: every shard draws its own noise
     use_graph = not args.no_graph
+    # the pool bound as a resident split: the step's first launch gathers its batch on the device (batch k = rows of pool[k % 4]),
+    # as the trainer does with the epoch's shuffled order (GANDataset.bind) -- no host-side staging launch between steps
+    bound = [torch.cat([b[j] for b in pool]) for j in range(4)]
+    eng.bind_batches(*bound)
 
     def step(i):
-        eng.set_batch(*pool[i % len(pool)])
-        dp.step(use_graph)        # melo-gan_amd/gan/dp.py: the graphs of one step and, for N > 1, the overlapped all-reduces
+        dp.step(use_graph)        # melo-gan_amd/gan/dp.py: the graphs of one step and, for N > 1, the in-graph collectives
+
+    def local_step():
+        """One eager step of the production launch sequence on THIS rank alone: no collectives of any kind."""
+        keep = (eng.coll, eng.p2_world, eng.world_size)
+        eng.coll, eng.p2_world = None, 0
+        try:
+            DataParallel(eng, 1, None).step(False)
+        finally:
+            eng.coll, eng.p2_world, eng.world_size = keep
 
     def barrier():
         if dist_on:
@@ -386,14 +398,12 @@ def main():
         if args.profile_steps > 0:
             iters = max(4, min(20, args.steps // 5))
             for k in range(2 * 5):
-                eng.set_batch(*pool[k % len(pool)])
                 dp.step(use_graph, g_step=(k % 5 == 4))
             torch.cuda.synchronize()
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(iters * 5):
-                eng.set_batch(*pool[k % len(pool)])
                 dp.step(use_graph, g_step=(k % 5 == 4))
             torch.cuda.synchronize()
             barrier()
@@ -412,12 +422,10 @@ def main():
         if rank == 0 and args.profile_steps > 0:
             hook = RecordHook(DOMINANT + CONV16)
             ops.set_launch_hook(hook)
-            eng.set_batch(*pool[0])
-            # the production launch sequence of one step, eagerly (the hook sees every launch) -- through a LOCAL wrapper:
-            # only rank 0 runs this leg, so it must not issue collectives (it did in an earlier version of this file and
-            # would have left rank 0 waiting for the others in every N > 1 run)
-            DataParallel(eng, 1, None).step(False)
-            eng.world_size = world
+            # the production launch sequence of one step, eagerly (the hook sees every launch) -- through a LOCAL wrapper and
+            # with the engine's in-graph collectives switched off: only rank 0 runs this leg, so it must not issue
+            # collectives (it did in an earlier version of this file and would have left rank 0 waiting for the others)
+            local_step()
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
 
@@ -449,8 +457,7 @@ def main():
                 t["gflop_per_step"] += flops / 1e9
                 return ops._NullCtx()
             ops.set_launch_hook(count)
-            eng.set_batch(*pool[0])
-            DataParallel(eng, 1, None).step(False)
+            local_step()
             torch.cuda.synchronize()
             ops.set_launch_hook(None)
             with open(args.launch_flops, "w") as f:
@@ -465,17 +472,16 @@ def main():
             eng2 = GanEngine(cfg, ed_cfg, f"cuda:{local_rank}", B_PER_GPU, ed_dtype="bf16")
             eng2.init_weights(seed=42)
             eng2.seed(1234)
+            eng2.bind_batches(*bound)
             dp2 = DataParallel(eng2, 1, None)
             n2 = max(args.steps, 64)
             with torch.cuda.stream(eng2.stream):
                 for i in range(5):
-                    eng2.set_batch(*pool[i % len(pool)])
                     dp2.step(True)
                 torch.cuda.synchronize()
                 evs = [ops.Event() for _ in range(n2 + 1)]
                 evs[0].record()
                 for i in range(n2):
-                    eng2.set_batch(*pool[i % len(pool)])
                     dp2.step(True)
                     evs[i + 1].record()
                 torch.cuda.synchronize()

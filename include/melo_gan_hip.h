@@ -157,7 +157,8 @@ int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups
  *      classifier's tail (ed_model.py:61,86-95,147-165: project, MLP, head, cross-entropy and their data-gradients) and the
  *      critic's tail (src/gan/models.py:149-169: fc, scoring head and their data-gradients).  Row r of every global operand
  *      is at ptr + r * ld.  Ops (fields not named are ignored):
- *   LOAD       slot b [0,n0) (+= if i0) p0 row (r % i1 if i1 > 0)
+ *   LOAD       slot b [n1, n1+n0) (+= if i0) p0 row (r % i1 if i1 > 0)
+ *   COPY       slot b [n1, n1+n0) = slot a [i1, i1+n0)
  *   STORE      q0 row <- slot a [0,n0)
  *   MEAN_T     slot b [0,n0) = mean over t < i0 of p0[(r*i0 + t)*ld0 + c]  (AdaptiveAvgPool1d(1) of a (rows, i0, ld0) tensor); q0 rows <- it
  *   LAYERNORM  slot b = LN(slot a [0,n0<=64)) * p0 + p1, eps f0; q0 rows <- xhat, q1 rows <- output (optional)
@@ -173,7 +174,7 @@ int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups
 #define MG_CHAIN_SLOTS 6
 #define MG_CHAIN_MAX_VEC 512
 enum { MG_CH_LOAD = 1, MG_CH_STORE = 2, MG_CH_LAYERNORM = 3, MG_CH_LIN_FWD = 4, MG_CH_LIN_DGRAD = 5, MG_CH_SOFTMAX_CE = 6,
-       MG_CH_DHEAD = 7, MG_CH_MEAN_T = 8 };
+       MG_CH_DHEAD = 7, MG_CH_MEAN_T = 8, MG_CH_COPY = 9 };
 typedef struct mg_chain_op {
     int kind;
     int a, b;
@@ -411,6 +412,14 @@ typedef struct mg_stage_job {
     long rows;          /* rows of THIS job (<= n_rows); 0 = n_rows */
 } mg_stage_job;
 int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t stream);
+/* The same with the source rows picked on the DEVICE: row r of every job comes from position
+ *   p = ((counter[0] - base[0]) * n_rows + r) mod order_len   of the epoch's order (order[p]; NULL = the identity),
+ * i.e. batch number (counter - base) of an HBM-resident split's shuffled order (the DataLoader's sampler,
+ * src/gan/train_gan.py:80) -- so that a captured training step stages its own batch on every replay, with no host launch
+ * between steps.  counter is advanced by another launch of the step (the Philox step counter doubles as batch counter);
+ * the host writes `order` and `base` once per epoch.  Jobs carry no idx / rows of their own. */
+int mg_stage_rows_cursor(const mg_stage_job* jobs, int n_jobs, int n_rows, const int64_t* order, long order_len,
+                         const uint64_t* counter, const uint64_t* base, mg_stream_t stream);
 
 /* ---- per-step random inputs (replaces torch.randn / torch.rand / nn.Dropout's bernoulli draws:
  *      src/gan/train_gan.py:188,218; src/gan/utils.py:76; src/gan/feature_encoder.py:34) in ONE launch:

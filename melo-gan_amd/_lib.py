@@ -34,7 +34,7 @@ class ChainOp(C.Structure):
                 ("q0", vp), ("lq0", i64), ("q1", vp), ("lq1", i64), ("t0", vp)]
 
 
-CH_LOAD, CH_STORE, CH_LAYERNORM, CH_LIN_FWD, CH_LIN_DGRAD, CH_SOFTMAX_CE, CH_DHEAD, CH_MEAN_T = 1, 2, 3, 4, 5, 6, 7, 8
+CH_LOAD, CH_STORE, CH_LAYERNORM, CH_LIN_FWD, CH_LIN_DGRAD, CH_SOFTMAX_CE, CH_DHEAD, CH_MEAN_T, CH_COPY = 1, 2, 3, 4, 5, 6, 7, 8, 9
 CHAIN_MAX_OPS, CHAIN_SLOTS, CHAIN_MAX_VEC = 16, 6, 512
 
 
@@ -121,6 +121,7 @@ SIGNATURES = {
     "mg_copy_cols": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
     "mg_transpose_bcl_blc": (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
     "mg_stage_rows": (i32, [vp, i32, i32, vp]),
+    "mg_stage_rows_cursor": (i32, [vp, i32, i32, vp, i64, vp, vp, vp]),
     "mg_act_bwd": (i32, [vp, vp, i32, vp, vp, i64, vp]),
     "mg_rng_fill": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp]),
     "mg_rng_fill_tick": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, f32, f32, vp]),

@@ -190,12 +190,16 @@ __global__ __launch_bounds__(CH_THREADS) void row_chain_kernel(const ChainArgs A
     for (int q = 0; q < A.n_ops; ++q) {
         const mg_chain_op& o = A.op[q];
         switch (o.kind) {
-            case MG_CH_LOAD: {       // slot[b][j] (+)= p0[(row % i1) * ld0 + j]
+            case MG_CH_LOAD: {       // slot[b][n1 + j] (+)= p0[(row % i1) * ld0 + j], j < n0
                 const long r = o.i1 > 0 ? row % o.i1 : row;
                 for (int j = tid; j < o.n0; j += CH_THREADS) {
                     const float v = o.p0[r * o.ld0 + j];
-                    slot[o.b][j] = o.i0 ? slot[o.b][j] + v : v;
+                    slot[o.b][o.n1 + j] = o.i0 ? slot[o.b][o.n1 + j] + v : v;
                 }
+                break;
+            }
+            case MG_CH_COPY: {       // slot[b][n1 + j] = slot[a][i1 + j], j < n0 (a != b)
+                for (int j = tid; j < o.n0; j += CH_THREADS) slot[o.b][o.n1 + j] = slot[o.a][o.i1 + j];
                 break;
             }
             case MG_CH_MEAN_T: {     // slot[b][c] = (1/i0) sum_t p0[(row*i0 + t)*ld0 + c], c < n0: AdaptiveAvgPool1d(1); q0 rows <- it
@@ -367,7 +371,12 @@ extern "C" int mg_row_chain(const mg_chain_op* ops, int n_ops, int rows, mg_stre
         auto slot_ok = [](int s) { return s >= 0 && s < CH_SLOTS; };
         switch (o.kind) {
             case MG_CH_LOAD:
-                MG_CHECK_ARG(o.p0 && slot_ok(o.b) && vec_ok(o.n0) && o.ld0 >= o.n0 && o.i1 >= 0, "mg_row_chain: op %d (load)", i);
+                MG_CHECK_ARG(o.p0 && slot_ok(o.b) && vec_ok(o.n0) && o.n1 >= 0 && o.n1 + o.n0 <= CH_MAXV && o.ld0 >= o.n0 && o.i1 >= 0,
+                             "mg_row_chain: op %d (load)", i);
+                break;
+            case MG_CH_COPY:
+                MG_CHECK_ARG(slot_ok(o.a) && slot_ok(o.b) && o.a != o.b && vec_ok(o.n0) && o.n1 >= 0 && o.n1 + o.n0 <= CH_MAXV &&
+                             o.i1 >= 0 && o.i1 + o.n0 <= CH_MAXV, "mg_row_chain: op %d (copy)", i);
                 break;
             case MG_CH_MEAN_T:
                 MG_CHECK_ARG(o.p0 && slot_ok(o.b) && vec_ok(o.n0) && o.ld0 >= o.n0 && o.i0 > 0 && (!o.q0 || o.lq0 >= o.n0),

@@ -844,6 +844,29 @@ __global__ void stage_rows_kernel(const StageJobs J, int n_rows) {
         for (long i = first; i < n; i += stride) reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
     }
 }
+// The same with the source rows picked by a DEVICE-side cursor: position p = ((counter - base) * n_rows + r) mod order_len of
+// the epoch's order (order == nullptr: the identity), so a captured training step stages its own batch on every replay --
+// no host-side launch between steps.  The counter is advanced by another kernel of the step (the critic's Adam launch
+// advances the Philox step counter, which doubles as the batch counter).
+__global__ void stage_rows_cursor_kernel(const StageJobs J, int n_rows, const int64_t* __restrict__ order, long order_len,
+                                         const unsigned long long* __restrict__ counter, const unsigned long long* __restrict__ base) {
+    const mg_stage_job job = J.j[blockIdx.z];
+    const int r = blockIdx.y;
+    const unsigned long long k = counter[0] - base[0];
+    const long pos = (long)((k * (unsigned long long)n_rows + (unsigned long long)r) % (unsigned long long)order_len);
+    long sr = order ? order[pos] : pos;
+    sr = sr < 0 ? 0 : (sr >= job.src_rows ? job.src_rows - 1 : sr);
+    const char* s = static_cast<const char*>(job.src) + sr * job.row_bytes;
+    char* d = static_cast<char*>(job.dst) + (long)r * (job.dst_pitch ? job.dst_pitch : job.row_bytes);
+    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)job.row_bytes) & 15) == 0) {
+        const long n = job.row_bytes >> 4;
+        for (long i = first; i < n; i += stride) reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+    } else {
+        const long n = job.row_bytes >> 2;
+        for (long i = first; i < n; i += stride) reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
+    }
+}
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int L,
                                  const float* __restrict__ gref, int gact) {
     __shared__ float tile[32][33];
@@ -1398,6 +1421,31 @@ int mg_stage_rows(const mg_stage_job* jobs, int n_jobs, int n_rows, mg_stream_t 
     bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
     hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)bx, (unsigned)n_rows, (unsigned)n_jobs), dim3(256), 0, ST, J, n_rows);
     MG_CHECK_LAUNCH("stage_rows");
+    return MG_OK;
+}
+
+int mg_stage_rows_cursor(const mg_stage_job* jobs, int n_jobs, int n_rows, const int64_t* order, long order_len,
+                         const uint64_t* counter, const uint64_t* base, mg_stream_t stream) {
+    MG_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= MG_MAX_STAGE_JOBS && n_rows > 0 && n_rows <= 65535 && order_len > 0 && counter && base,
+                 "mg_stage_rows_cursor: need 1..%d jobs, 1..65535 rows, a positive order length, counter and base", MG_MAX_STAGE_JOBS);
+    StageJobs J = {};
+    long widest = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const mg_stage_job& j = jobs[i];
+        MG_CHECK_ARG(j.src && j.dst && j.row_bytes > 0 && (j.row_bytes & 3) == 0 && j.src_rows > 0 && !j.idx && j.rows == 0 &&
+                         ((((uintptr_t)j.src | (uintptr_t)j.dst)) & 3) == 0 && (order || j.src_rows >= order_len),
+                     "mg_stage_rows_cursor: job %d: 4-byte aligned rows of a multiple of 4 bytes, no per-job index / row count, and "
+                     "without an order array the source must hold order_len rows", i);
+        MG_CHECK_ARG(j.dst_pitch == 0 || (j.dst_pitch >= j.row_bytes && (j.dst_pitch & 3) == 0),
+                     "mg_stage_rows_cursor: job %d: dst_pitch must be 0 or a multiple of 4 that holds a row", i);
+        J.j[i] = j;
+        widest = j.row_bytes > widest ? j.row_bytes : widest;
+    }
+    long bx = mg_cdiv(widest >> 4, 256);
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    hipLaunchKernelGGL(stage_rows_cursor_kernel, dim3((unsigned)bx, (unsigned)n_rows, (unsigned)n_jobs), dim3(256), 0, ST, J, n_rows,
+                       order, order_len, (const unsigned long long*)counter, (const unsigned long long*)base);
+    MG_CHECK_LAUNCH("stage_rows_cursor");
     return MG_OK;
 }
 

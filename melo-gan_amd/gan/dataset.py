@@ -100,6 +100,29 @@ class GANDataset:
     def __len__(self):
         return self.n
 
+    # ---- the resident split bound to an engine: every training step stages its own batch on the device ----
+    def bind(self, eng, batch_size: int, rank: int = 0, world: int = 1) -> int:
+        """Bind the resident arrays to `eng` (GanEngine.bind_batches): the step's first launch gathers batch k of the
+        epoch's order itself.  Returns the batches this rank takes per epoch (drop_last; a trailing incomplete round of
+        ranks is dropped so that all ranks issue the same collectives)."""
+        if not self.resident:
+            raise ValueError("GANDataset.bind: only an HBM-resident split can be bound (streamed splits use batches())")
+        nb = self.n // batch_size
+        self._bind = (int(batch_size), int(rank), int(world), (nb - nb % world) // world)
+        if self._bind[3] < 1:
+            raise ValueError("GANDataset.bind: the split holds less than one batch per rank")
+        eng.bind_batches(self.notes, self.numeric, self.latent, self.emot_idx, order_len=self._bind[3] * batch_size)
+        return self._bind[3]
+
+    def start_epoch(self, eng, generator: Optional[torch.Generator] = None) -> int:
+        """A new shuffled order (the same permutation stream batches() draws from): this rank's batches rank, rank + world,
+        ... of it, written to the engine's order buffer with stream-ordered copies.  Returns the number of batches."""
+        B, rank, world, nb = self._bind
+        perm = torch.randperm(self.n, generator=generator)
+        idx = torch.cat([perm[g * B:(g + 1) * B] for g in range(rank, nb * world, world)])
+        eng.set_order(idx.to(self.device, non_blocking=True))
+        return nb
+
     def batches(self, batch_size: int, generator: Optional[torch.Generator] = None):
         """One epoch: shuffled, drop_last (train_gan.py:80).  Yields device tensors."""
         perm_host = torch.randperm(self.n, generator=generator)

@@ -326,6 +326,7 @@ class GanEngine:
                            all(ops.conv16_supported(nb, 4 * self.red, 64, C, True, 8 * self.red) for nb in (B, 2 * B)) and
                            os.environ.get("MELO_MIX_FUSED", "1") == "1")
         self._init_chains()
+        self._bound = None          # bind_batches(): the step stages its own batch
         # data parallelism with the collectives INSIDE the sub-steps (DataParallel, mode "ingraph"): an InGraphCollectives
         self.coll = None
         self._p2_pending = self._a_p0_gathered = False
@@ -374,6 +375,12 @@ class GanEngine:
         PE, PD, PED = self._ep, self.D.p, self.ED.p
         self._chain_e = (on and self.num_in <= 64 and Ch.supported(self.num_in, h1, h2, self.E, self.noise_dim, max(self.latent_dim, 1))
                          and Ch.weights_ok(PE("net.1.weight"), PE("net.4.weight"), PE("net.7.weight")))
+        PG = self._gp
+        # ... extended over the generator's small front layers (noise_to_latent, decoder.pre.0: models.py:20-27,47-48) and,
+        # backwards, their data-gradients: one launch from the numeric features to decoder.pre.2's input and back
+        self._chain_gf = (self._chain_e and Ch.supported(self.in_dim, 512, max(self.latent_dim, 1)) and self.latent_dim % 4 == 0
+                          and Ch.weights_ok(PG("noise_to_latent.net.0.weight"), PG("noise_to_latent.net.2.weight"),
+                                            PG("decoder.pre.0.weight")) and os.environ.get("MELO_CHAIN_GF", "1") == "1")
         self._chain_d = on and Ch.supported(256, self.E) and Ch.weights_ok(PD["fc.1.weight"])
         mh = tuple(self.ed_cfg.get("mlp_hidden", (256, 128)))
         ws = [PED[f"classifier.net.{3 * j}.weight"] for j in range(len(mh))] + [PED["classifier.head.weight"]]
@@ -534,6 +541,48 @@ class GanEngine:
             self.latent.copy_(latent, non_blocking=True)
         self.emot_idx.copy_(emot_idx, non_blocking=True)
 
+    def bind_batches(self, real: Tensor, numeric: Tensor, latent: Optional[Tensor], emot_idx: Tensor,
+                     order_len: Optional[int] = None):
+        """Bind an HBM-resident split (or pool of batches): from now on every batch's first sub-step (the draw of
+        d_backward_rng / dg_step_rng / ...) STAGES ITS OWN BATCH -- batch number (rng_step - batch_base) of the order written
+        by set_order() (default: the rows in sequence) -- as the first launch of its graph.  No set_batch() call, i.e. no
+        host-side launch and no extra graph boundary between steps (they cost ~20 us per step at cfg2).  The Philox step
+        counter, advanced by the critic's Adam launch once per batch, is the batch counter."""
+        srcs = [(real, self.real), (numeric, self.numeric_d), (numeric, self.numeric)]
+        if latent is not None and self.latent_dim > 0:
+            srcs.append((latent, self.latent))
+        srcs.append((emot_idx, self.emot_idx))
+        n = real.shape[0]
+        for s_, d_ in srcs:
+            if not (s_.is_cuda and s_.is_contiguous() and s_.dtype == d_.dtype and s_.shape[1:] == d_.shape[1:] and s_.shape[0] == n):
+                raise ValueError("bind_batches: contiguous device arrays of the engine's dtypes and row shapes, equal length")
+        self.batch_order_len = int(order_len or (n // self.B) * self.B)
+        if self.batch_order_len < self.B:
+            raise ValueError("bind_batches: fewer rows than one batch")
+        self.batch_order = torch.arange(self.batch_order_len, dtype=torch.int64, device=self.dev)
+        self.batch_base = self.rng_step.clone()
+        self._bound = srcs
+        if self._graphs and self.capture_locked:
+            raise RuntimeError("bind_batches: after DataParallel.prepare() -- bind the split before the first step")
+        self._graphs.clear()        # graphs captured before the binding do not stage
+
+    def set_order(self, order: Tensor):
+        """The epoch's order (int64 row indices, batch after batch; exactly batch_order_len of them): batch 0 of it is the
+        next batch staged.  Stream-ordered device copies -- no synchronisation."""
+        if self._bound is None or order.numel() != self.batch_order_len:
+            raise ValueError("set_order: bind_batches() first; the order must have batch_order_len entries")
+        self.batch_order.copy_(order.to(torch.int64), non_blocking=True)
+        self.batch_base.copy_(self.rng_step)
+
+    def unbind_batches(self):
+        self._bound = None
+        if not self.capture_locked:
+            self._graphs.clear()
+
+    def _stage_bound(self):
+        if self._bound is not None:
+            ops.stage_rows_cursor(self._bound, self.B, self.batch_order, self.batch_order_len, self.rng_step, self.batch_base)
+
     def set_randoms(self, noise: Tensor, drop_masks: Optional[Sequence[Tensor]], alpha: Optional[Tensor] = None,
                     half: Optional[str] = None):
         """Injected randomness of one sub-step.  drop_masks are {0,1} keep-masks (None => eval mode, no dropout).
@@ -552,6 +601,8 @@ class GanEngine:
         the Adam state of the optimiser this sub-step ends with (critic when alpha is drawn, generator otherwise), and
         that update advances the Philox step counter: no tick launches (see mg_rng_fill_tick)."""
         fp = self.D if with_alpha else self.GE
+        if with_alpha:
+            self._stage_bound()                   # a bound split: the batch's first sub-step stages it (bind_batches)
         # the two sub-steps draw from different Philox keys: under data parallelism the G-step's draw is issued before
         # the critic update has advanced the step counter (DataParallel.step)
         key = self.rng_seed if with_alpha else (self.rng_seed + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
@@ -563,6 +614,7 @@ class GanEngine:
     def draw_randoms_both(self):
         """The fused step's draw: noise and dropout masks of BOTH halves plus alpha in one launch, which advances both
         optimisers' Adam states; the critic update advances the Philox counter."""
+        self._stage_bound()
         ops.rng_fill(self.noise_2, self.alpha, self.dmask_2[0], self.dmask_2[1], P_DROP, self.rng_seed, self.rng_step,
                      tick_state=self.D.state, betas=self.betas, tick_state2=self.GE.state)
         self.D.ticked, self.GE.ticked = True, "nobump"
@@ -570,6 +622,8 @@ class GanEngine:
     def seed(self, seed: int):
         self.rng_seed = int(seed)
         self.rng_step.zero_()
+        if self._bound is not None:
+            self.batch_base.zero_()
 
     # -------------------------------------------------------------------------------------
     # forward pieces
@@ -600,6 +654,20 @@ class GanEngine:
             ch.linear_fwd(1, 2, P("net.1.weight"), P("net.1.bias"), ACT_GELU, m1, zout=v("e_z1"), out=v("e_h1"))
             ch.linear_fwd(2, 3, P("net.4.weight"), P("net.4.bias"), ACT_GELU, m2, zout=v("e_z2"), out=v("e_h2"))
             ch.linear_fwd(3, 4, P("net.7.weight"), P("net.7.bias"), out=v("emb"))
+            if gin and self._chain_gf:
+                # the generator's input assembled in LDS, then noise_to_latent and decoder.pre.0 in the same launch
+                nd, E, G = self.noise_dim, self.E, self._gp
+                ch.copy(4, 5, E, dst_at=nd)
+                ch.load(5, v("noise"))
+                if self.mode == "conditioning":
+                    ch.load(5, self.latent, mod=self.B, at=nd + E)      # the batch's latent, the same rows for both halves
+                ch.store(5, v("gin"))
+                ch.linear_fwd(5, 0, G("noise_to_latent.net.0.weight"), G("noise_to_latent.net.0.bias"), ACT_RELU, out=v("a_n0"))
+                ch.linear_fwd(0, 1, G("noise_to_latent.net.2.weight"), G("noise_to_latent.net.2.bias"), out=v("lat"))
+                ch.linear_fwd(1, 2, G("decoder.pre.0.weight"), G("decoder.pre.0.bias"), ACT_RELU, out=v("a_p0"))
+                ch.launch()
+                self._gin_done = "front"
+                return
             if gin:
                 nd, E, g = self.noise_dim, self.E, v("gin")
                 ch.store(4, g[:, nd:nd + E])
@@ -630,15 +698,17 @@ class GanEngine:
         if self.mode == "conditioning":
             for h in range(n // self.B):          # the batch's latent, once per half
                 blocks.append((self.latent, gin[h * self.B:(h + 1) * self.B, nd + E:nd + E + self.latent_dim], None))
-        if self._gin_done:
-            self._gin_done = False                  # assembled by the encoder's chain launch (_e_fwd(gin=True))
+        front, self._gin_done = self._gin_done, False
+        if front:
+            pass                                    # assembled by the encoder's chain launch (_e_fwd(gin=True))
         elif n == self.B:
             ops.stage_rows(blocks, n)
         else:       # one launch: the two-half blocks cover n rows, the per-half latent blocks B rows each
             ops.stage_rows(blocks[:2] + [(s_, d_, i_, self.B) for (s_, d_, i_) in blocks[2:]], n)
-        ops.linear_fwd(gin, P("noise_to_latent.net.0.weight"), v("a_n0"), bias=P("noise_to_latent.net.0.bias"), act=ACT_RELU)
-        ops.linear_fwd(v("a_n0"), P("noise_to_latent.net.2.weight"), v("lat"), bias=P("noise_to_latent.net.2.bias"))
-        ops.linear_fwd(v("lat"), P("decoder.pre.0.weight"), v("a_p0"), bias=P("decoder.pre.0.bias"), act=ACT_RELU)
+        if front != "front":                        # else noise_to_latent and pre.0 ran in that launch too
+            ops.linear_fwd(gin, P("noise_to_latent.net.0.weight"), v("a_n0"), bias=P("noise_to_latent.net.0.bias"), act=ACT_RELU)
+            ops.linear_fwd(v("a_n0"), P("noise_to_latent.net.2.weight"), v("lat"), bias=P("noise_to_latent.net.2.bias"))
+            ops.linear_fwd(v("lat"), P("decoder.pre.0.weight"), v("a_p0"), bias=P("decoder.pre.0.bias"), act=ACT_RELU)
         if n <= ops.SKINNY_MAX_ROWS and self.red > 1:
             # pre.2's output straight into the channels-last (rows, L, 256) tensor the first deconvolution reads
             # (models.py:70-73: view(B, 256, L) + permute): the Linear launch walks its weight rows in that order
@@ -1151,19 +1221,41 @@ class GanEngine:
                                       defer=True))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
         jobs.append(ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"), defer=True))
-        ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
-        if self.ed_mode != "notes":
-            ops.axpby(self.ed_dfeat, self.d_lat, 1.0, 1.0)
         jobs.append(ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"),
                                      db=GG("noise_to_latent.net.2.bias"), defer=True))
-        ops.linear_dgrad(self.d_lat, PG("noise_to_latent.net.2.weight"), self.d_n0, gref=self.a_n0, gact=ACT_RELU)
         jobs.append(ops.linear_wgrad(self.gin, self.d_n0, GG("noise_to_latent.net.0.weight"),
                                      db=GG("noise_to_latent.net.0.bias"), defer=True))
-        ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
         # embedding gradient = generator-input slice + critic-head path, then E_num backward
         jobs.append(ops.linear_wgrad(self.e_h2, self.demb, GEg("net.7.weight"), db=GEg("net.7.bias"), defer=True))
         jobs.append(ops.linear_wgrad(self.e_h1, self.d_ez2, GEg("net.4.weight"), db=GEg("net.4.bias"), defer=True))
         jobs.append(ops.linear_wgrad(self.e_x0, self.d_ez1, GEg("net.1.weight"), db=GEg("net.1.bias"), defer=True))
+        if self._chain_gf:
+            # pre.0's, noise_to_latent's and the numeric encoder's data-gradients as ONE launch: from decoder.pre.2's input
+            # gradient back to the LayerNorm output's (models.py:20-27,47-48 and feature_encoder.py:16-42 backwards)
+            nd = self.noise_dim
+            ch = ops.Chain(B)
+            ch.load(0, self.d_p0)
+            ch.linear_dgrad(0, 1, PG("decoder.pre.0.weight"), out=self.d_lat)
+            if self.ed_mode != "notes":
+                ch.load(1, self.ed_dfeat, accumulate=True)
+                ch.store(1, self.d_lat)
+            ch.linear_dgrad(1, 2, PG("noise_to_latent.net.2.weight"), gref=self.a_n0, gact=ACT_RELU, out=self.d_n0)
+            ch.linear_dgrad(2, 3, PG("noise_to_latent.net.0.weight"), out=self.d_gin)
+            ch.copy(3, 4, self.E, src_at=nd)
+            ch.load(4, self.demb, accumulate=True)
+            ch.store(4, self.demb)
+            ch.linear_dgrad(4, 5, PE("net.7.weight"), gref=self.e_z2, gact=ACT_GELU, mask=self.dmask[1], out=self.d_ez2)
+            ch.linear_dgrad(5, 0, PE("net.4.weight"), gref=self.e_z1, gact=ACT_GELU, mask=self.dmask[0], out=self.d_ez1)
+            ch.linear_dgrad(0, 1, PE("net.1.weight"), out=self.d_ex0)
+            ch.launch()
+            ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
+            ops.wgrad_multi(jobs)
+            return
+        ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
+        if self.ed_mode != "notes":
+            ops.axpby(self.ed_dfeat, self.d_lat, 1.0, 1.0)
+        ops.linear_dgrad(self.d_lat, PG("noise_to_latent.net.2.weight"), self.d_n0, gref=self.a_n0, gact=ACT_RELU)
+        ops.linear_dgrad(self.d_n0, PG("noise_to_latent.net.0.weight"), self.d_gin)
         if self._chain_e:           # the encoder's data-gradient chain as one launch (feature_encoder.py:16-42 backwards)
             ch = ops.Chain(B)
             ch.load(0, self.d_gin[:, self.noise_dim:self.noise_dim + self.E])

@@ -219,20 +219,32 @@ def train(cfg: dict, ed_cfg: dict, ed_ckpt: str, synthetic: int = 0, use_graph: 
     sums = torch.zeros(3, device=device)        # sum loss_d, sum g_adv, sum g_emo (device-side accumulation)
     shuffle_gen = torch.Generator().manual_seed(cfg.get("SEED", 42))
     log("Starting WGAN-GP Training with Emotion Guidance...")
+
+    def epoch_batches():
+        """Per batch of this rank's share of the epoch: stage it (or, for a bound resident split, nothing: the step's first
+        launch gathers batch k of the epoch's order on the device) and yield its index."""
+        if ds.resident:
+            for k in range(ds.start_epoch(eng, shuffle_gen)):
+                yield k
+            return
+        # every rank walks the same shuffled order and takes the batches rank, rank + world, ...; a trailing
+        # incomplete round is dropped so that all ranks issue the same collectives
+        usable = len(ds) // B - (len(ds) // B) % world
+        for gi, batch in enumerate(ds.batches(B, shuffle_gen)):
+            if gi >= usable:
+                break
+            if gi % world != rank:
+                continue
+            batch.stage(eng)           # one gather launch from the streamed rolls into the engine's buffers
+            yield gi // world
+
     with torch.cuda.stream(eng.stream):
+        if ds.resident:
+            ds.bind(eng, B, rank, world)
         for epoch in range(start_epoch + 1, cfg["EPOCHS"] + 1):
             sums.zero_()
             steps = 0
-            # every rank walks the same shuffled order and takes the batches rank, rank + world, ...; a trailing
-            # incomplete round is dropped so that all ranks issue the same collectives
-            usable = len(ds) // B - (len(ds) // B) % world
-            for gi, batch in enumerate(ds.batches(B, shuffle_gen)):
-                if gi >= usable:
-                    break
-                if gi % world != rank:
-                    continue
-                batch_idx = gi // world
-                batch.stage(eng)           # one gather launch from the resident arrays into the engine's buffers
+            for batch_idx in epoch_batches():
                 g_step = (batch_idx + 1) % critic_iters == 0
                 dp.step(use_graph, g_step)
                 sums[0:1] += eng.loss_d_out[0:1]

@@ -430,11 +430,23 @@ class Chain:
         self.ops.append(o)
         return o
 
-    def load(self, slot, t, n=None, accumulate=False, mod=0):
+    def load(self, slot, t, n=None, accumulate=False, mod=0, at=0):
+        """slot[at : at + n] (+)= row of t (row r % mod if mod)."""
         n = t.shape[1] if n is None else n
+        if at < 0 or at + n > L.CHAIN_MAX_VEC:
+            raise ValueError("chain load: destination range exceeds the slot")
         o = self._op(L.CH_LOAD, b=slot, n0=n)
+        o.n1 = int(at)
         o.p0, o.ld0 = self._rows(t, "load", n, rows=mod or None)
         o.i0, o.i1 = (1 if accumulate else 0), int(mod)
+        return self
+
+    def copy(self, src, dst, n, src_at=0, dst_at=0):
+        """slot dst[dst_at : dst_at + n] = slot src[src_at : src_at + n]."""
+        if src == dst or min(src_at, dst_at) < 0 or max(src_at, dst_at) + n > L.CHAIN_MAX_VEC:
+            raise ValueError("chain copy: bad ranges")
+        o = self._op(L.CH_COPY, a=src, b=dst, n0=n)
+        o.n1, o.i1 = int(dst_at), int(src_at)
         return self
 
     def store(self, slot, t, n=None):
@@ -1132,6 +1144,35 @@ def stage_rows(jobs, n_rows):
         a.dst_pitch = 0 if dense else dst.stride(0) * dst.element_size()
         a.rows = 0 if jrows == n_rows else jrows
     L.check(L.load().mg_stage_rows(arr, len(jobs), n_rows, _stream()), "mg_stage_rows")
+
+
+def stage_rows_cursor(jobs, n_rows, order, order_len, counter, base):
+    """stage_rows with the source rows picked on the device (mg_stage_rows_cursor): for every (src, dst) in `jobs`,
+    dst[r] = src[order[p]] (order None: src[p]) with p = ((counter - base) * n_rows + r) % order_len.  counter / base: int64
+    device scalars (1,)."""
+    if not 0 < len(jobs) <= L.MAX_STAGE_JOBS:
+        raise ValueError(f"stage_rows_cursor: 1..{L.MAX_STAGE_JOBS} jobs")
+    _chk(counter, "counter", (1,), torch.int64)
+    _chk(base, "base", (1,), torch.int64)
+    if order is not None:
+        _chk(order, "order", dtype=torch.int64)
+        if order.numel() < order_len:
+            raise ValueError("stage_rows_cursor: order shorter than order_len")
+    arr = (L.StageJob * len(jobs))()
+    for a, (src, dst) in zip(arr, jobs):
+        if not (isinstance(src, torch.Tensor) and src.is_cuda and src.is_contiguous() and src.dim() >= 1):
+            raise ValueError("stage_rows_cursor: src must be a contiguous device tensor")
+        if not (isinstance(dst, torch.Tensor) and dst.is_cuda and dst.is_contiguous() and dst.dim() >= 1):
+            raise ValueError("stage_rows_cursor: dst must be a contiguous device tensor")
+        if src.dtype != dst.dtype or src.shape[1:] != dst.shape[1:] or dst.shape[0] < n_rows:
+            raise ValueError(f"stage_rows_cursor: row mismatch {tuple(src.shape)} {src.dtype} -> {tuple(dst.shape)} {dst.dtype}")
+        if order is None and src.shape[0] < order_len:
+            raise ValueError("stage_rows_cursor: without an order the source must hold order_len rows")
+        a.src, a.dst, a.idx = src.data_ptr(), dst.data_ptr(), None
+        a.row_bytes, a.src_rows = src.element_size() * (src[0].numel() if src.dim() > 1 else 1), src.shape[0]
+        a.dst_pitch, a.rows = 0, 0
+    L.check(L.load().mg_stage_rows_cursor(arr, len(jobs), n_rows, _p(order), int(order_len), _p(counter), _p(base), _stream()),
+            "mg_stage_rows_cursor")
 
 
 def transpose_bcl_blc(x, y, gref=None, gact=ACT_NONE):

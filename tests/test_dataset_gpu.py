@@ -85,3 +85,43 @@ def test_batch_stage_fills_the_engine_like_set_batch():
             assert torch.equal(got[0], notes) and torch.equal(got[3], emot)
             seen += 1
         assert seen == 50 // B
+
+
+def test_bound_split_stages_its_batches_inside_the_step():
+    """GanEngine.bind_batches / GANDataset.bind: the first launch of every batch's graph gathers batch k of the epoch's
+    order on the device (the Philox step counter is the batch counter) -- equal to set_batch(idx) of the same indices, under
+    graph replay, across an epoch change, for critic-only and critic+generator batches."""
+    import melo_gan_amd  # noqa: F401
+    from melo_gan_amd.gan.dataset import GANDataset
+    from melo_gan_amd.gan.engine import GanEngine
+    from melo_gan_amd.gan.dp import DataParallel
+    from oracle import melo_oracle as O
+    B, T, C, N = 4, 32, 4, 22
+    cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
+    ds = GANDataset.synthetic(N, T, C, cfg["LATENT_DIM"], 3, "cuda")
+    engs = []
+    for _ in range(2):
+        e = GanEngine(cfg, ed_cfg, "cuda", B)
+        e.init_weights(1)
+        e.seed(11)
+        engs.append(e)
+    bound, plain = engs
+    dpb, dpp = DataParallel(bound, 1, None), DataParallel(plain, 1, None)
+    gen_b, gen_p = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    with torch.cuda.stream(bound.stream):
+        nb = ds.bind(bound, B)
+        assert nb == N // B
+        for epoch in range(3):
+            assert ds.start_epoch(bound, gen_b) == nb
+            batches = list(ds.batches(B, gen_p))
+            for k in range(nb):
+                g_step = k % 2 == 1
+                dpb.step(True, g_step)
+                batches[k].stage(plain)
+                dpp.step(True, g_step)
+                torch.cuda.synchronize()
+                assert torch.equal(bound.real, plain.real) and torch.equal(bound.numeric, plain.numeric) and torch.equal(bound.numeric_d, plain.numeric_d)
+                assert torch.equal(bound.emot_idx, plain.emot_idx) and torch.equal(bound.latent, plain.latent)
+        torch.cuda.synchronize()
+    assert torch.equal(bound.D.data, plain.D.data) and torch.equal(bound.GE.data, plain.GE.data)
+    assert int(bound.rng_step.item()) == 3 * nb

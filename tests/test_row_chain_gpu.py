@@ -174,14 +174,15 @@ def test_engine_with_chains_equals_the_per_layer_launches(B, T, C):
         e.g_backward_a2()
         e.g_backward_b()
     torch.cuda.synchronize()
-    for name in ("emb_2", "gin_2", "e_z1_2", "e_h2_2", "Fh", "s", "logits", "dlogits", "ed_pool", "ed_proj", "ed_dpool", "loss_d_out",
+    assert e1._chain_gf and not e0._chain_gf
+    for name in ("emb_2", "gin_2", "e_z1_2", "e_h2_2", "a_n0_2", "lat_2", "a_p0_2", "Fh", "s", "logits", "dlogits", "ed_pool", "ed_proj", "ed_dpool", "loss_d_out",
                  "adv", "emo", "notes"):
         a, b = getattr(e1, name), getattr(e0, name)
         close(a, b, 2e-5)
     # behind the critic's LeakyReLU masks: a pre-activation within rounding of 0 lands on the other side of the kink under
     # another summation order (the head's dU = ds * w * lrelu'(Fh) then differs by 0.8 * |ds w| in that element): a
     # handful of the 49k elements at cfg2, a valid subgradient either way (tests/test_fullsize_gpu.py has the same allowance)
-    for name in ("dU", "dH", "demb", "d_ez2", "d_ez1", "d_ex0", "dnotes"):
+    for name in ("dU", "dH", "d_lat", "d_n0", "d_gin", "demb", "d_ez2", "d_ez1", "d_ex0", "dnotes"):
         close(getattr(e1, name), getattr(e0, name), 5e-3)
     flips = float(((e1.Fh > 0) != (e0.Fh > 0)).float().mean())
     assert flips < 1e-3, flips
