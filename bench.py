@@ -264,7 +264,7 @@ def side_workload(args):
             torch.cuda.synchronize()
             g = ops.Graph()
             g.begin()
-            eng._e_fwd(train=False); eng._g_fwd(eng.notes, train=False)
+            eng._e_fwd(train=False, gin=True); eng._g_fwd(eng.notes, train=False)
             g.end()
             lat = []
             for _ in range(1000):
@@ -364,6 +364,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i)
+        host_el = time.perf_counter() - t0           # the host's share: enqueueing K steps (it runs ahead of the GPU)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -517,6 +518,7 @@ def main():
                        "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
                        "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2),
                        "dp_mode": dp.mode if dp.active else None},
+            "host_ms_per_step": round(1e3 * host_el / args.steps, 4),
             "event_timing": event_timing, "roofline": roof, "roofline_stride2_family": roof2, "cpu_baseline": cpu,
             "secondary_bf16_ed": sec,
             "secondary": sched,

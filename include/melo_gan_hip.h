@@ -489,6 +489,8 @@ int mg_vae_loss(const float* recon, const float* x, long n_x, const float* mu, c
 /* ---- hipGraph capture of a launch sequence issued through this library (or anything else on the stream) ---- */
 int mg_graph_begin(mg_stream_t stream);
 int mg_graph_end(mg_stream_t stream, void** graph_exec_out);
+/* mg_graph_end with the capture instantiated n (1..8) times (launches may then alternate between the executables). */
+int mg_graph_end_n(mg_stream_t stream, void** graph_execs_out, int n);
 int mg_graph_launch(void* graph_exec, mg_stream_t stream);
 int mg_graph_destroy(void* graph_exec);
 

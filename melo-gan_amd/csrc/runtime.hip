@@ -34,6 +34,26 @@ int mg_graph_end(mg_stream_t stream, void** graph_exec_out) {
     *graph_exec_out = (void*)exec;
     return MG_OK;
 }
+// The same capture instantiated `n` times (an experiment knob: alternating executables of the step graph measured slower
+// than replaying one, melo-gan_amd/ops.py::Graph).
+int mg_graph_end_n(mg_stream_t stream, void** graph_execs_out, int n) {
+    MG_CHECK_ARG(graph_execs_out != nullptr && n >= 1 && n <= 8, "mg_graph_end_n: 1..8 executables");
+    hipGraph_t graph = nullptr;
+    MG_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+    for (int i = 0; i < n; ++i) {
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            for (int j = 0; j < i; ++j) hipGraphExecDestroy((hipGraphExec_t)graph_execs_out[j]);
+            hipGraphDestroy(graph);
+            mg_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            return MG_EHIP;
+        }
+        graph_execs_out[i] = (void*)exec;
+    }
+    hipGraphDestroy(graph);
+    return MG_OK;
+}
 int mg_graph_launch(void* graph_exec, mg_stream_t stream) {
     MG_CHECK_ARG(graph_exec != nullptr, "mg_graph_launch: null graph");
     MG_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));

@@ -156,7 +156,10 @@ class DataParallel:
         # split | ingraph | none.  Default: the split flow for the fp32 engine; the bf16-stored emotion branch is a third as
         # long and the three extra graph launches cost more than hiding it returns (0.831 -> 0.872 ms): it forks inside
         # the one graph instead (0.770)
-        self._ed_flow = os.environ.get("MELO_ED_FLOW") or ("split" if getattr(engine, "ed_dtype", "fp32") == "fp32" else "ingraph")
+        self._ed_flow = os.environ.get("MELO_ED_FLOW") or "ingraph"
+        # (round 2 took "split" for the fp32 engine: 96 launches per step made the forked graph's launch cost the host 0.87 ms,
+        #  more than the GPU step; at 60 launches the host is back ahead and one graph with the fork inside beats the four
+        #  graphs of the split flow by their three extra boundaries: 0.886 -> 0.868 ms per step)
 
     def _backend(self):
         try:
@@ -291,6 +294,10 @@ class DataParallel:
                 e.run("d_step_g_critic_front", True)
                 cur.wait_stream(side)
                 e.run("g_finish", True)
+                return
+            if back_to_back and use_graph and side is not None and self._ed_flow == "fork2":
+                e.run("dg_forward_rng", True)
+                e.run("dg_fork_rest", True)
                 return
             if back_to_back and use_graph and side is not None and self._ed_flow == "ingraph":
                 e.run("dg_fork_step_rng", True)       # the branch inside the one graph (GanEngine.dg_fork_step_rng)

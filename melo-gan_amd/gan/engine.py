@@ -316,6 +316,10 @@ class GanEngine:
         # side stream of the fused step's emotion branch (dg_step_rng); MELO_ED_SIDE=0: everything on one stream
         self.ed_side = torch.cuda.Stream(device=d) if os.environ.get("MELO_ED_SIDE", "1") == "1" else None
         self.ed_side_lds_pad = int(os.environ.get("MELO_ED_LDS_PAD", "42000"))      # g_ed_branch_side
+        # its data-gradient convolutions: the same cap.  (In the forked-graph flow they mostly run after the main branch has
+        # reached the join, yet lifting the cap for them measured SLOWER: 0.867 -> 0.882 ms per step; alone on the chip a
+        # capped launch is only 8-10 % slower, tools/ed_pad_bench.py.)
+        self.ed_side_lds_pad_bwd = int(os.environ.get("MELO_ED_LDS_PAD_BWD", str(self.ed_side_lds_pad)))
         # (Forked side streams for independent branches of a step were implemented and measured in round 1: every
         # fork/join cost more cross-queue latency than the overlap returned once the kernels filled the chip -- 1.70 ms
         # single-stream vs 1.73-1.82 -- and were removed; independent launches of one kernel share a launch instead.)
@@ -327,6 +331,7 @@ class GanEngine:
                            os.environ.get("MELO_MIX_FUSED", "1") == "1")
         self._init_chains()
         self._bound = None          # bind_batches(): the step stages its own batch
+        self._il = None             # the emotion branch's launch generator while a forked graph is captured interleaved
         # data parallelism with the collectives INSIDE the sub-steps (DataParallel, mode "ingraph"): an InGraphCollectives
         self.coll = None
         self._p2_pending = self._a_p0_gathered = False
@@ -411,6 +416,15 @@ class GanEngine:
         def __init__(self):
             self.parts, self.pooled, self.perm, self.mixed = None, False, False, False
 
+    def _tick(self):
+        """Interleaved capture of the forked step graph (dg_fork_step_rng): after a main-branch convolution launch, issue the
+        emotion branch's next launch on the side stream."""
+        il = self._il
+        if il is not None:
+            with torch.cuda.stream(self.ed_side):
+                if next(il, "done") == "done":
+                    self._il = None
+
     def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, stats=None, pool=None, perm=False,
                  mix=None, **epi):
         """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
@@ -449,6 +463,7 @@ class GanEngine:
                 kw["mix"] = mix
                 res.mixed = True
             ops.conv16(x, wq, y, N, transposed, odd=odd, **kw)
+            self._tick()
             return res
         if perm:
             return res                              # not launched: the caller's transpose route
@@ -977,12 +992,46 @@ class GanEngine:
         self.dg_forward()
         cur = torch.cuda.current_stream()
         self.ed_side.wait_stream(cur)                 # fork
+        # capture order of the two branches: the one captured second starts ~170 us after the fork (kernel trace); the main
+        # branch first measured 0.866 ms per step, the emotion branch first 0.881 (MELO_FORK_ORDER, round 3)
+        self._fork_branches()
+        cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
+        self.g_critic_back()
+        self.g_backward_b()
+        self.g_update()
+
+    def _fork_branches(self):
+        """The two parallel branches between fork and join.  A forked hipGraph is fed to the GPU node by node in CAPTURE order
+        at ~12 us of host time per node (kernel trace: the branch captured second started 170 us after the fork and the
+        other then waited 190 us for it at the join) -- REGARDLESS of the capture order: interleaving the two branches' launches
+        in the capture (MELO_FORK_ORDER=interleave) measured the same as main_first (0.866 ms), ed_first 0.881: the runtime
+        feeds the origin stream's chain first.  Default main_first."""
+        order = os.environ.get("MELO_FORK_ORDER", "main_first")
+        if order == "ed_first" or (order == "interleave" and not self._chain_ed):
+            with torch.cuda.stream(self.ed_side):
+                self.g_ed_branch_side()
+            order = "done"
+        if order == "interleave":
+            self._require_fold()
+            self._il = self._ed_steps(self.ed_side_lds_pad, self.ed_side_lds_pad_bwd)
         self.d_backward(forward=False)
         self.d_update()
         self.g_critic_front()
-        with torch.cuda.stream(self.ed_side):
-            self.g_ed_branch_side()
-        cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
+        if order == "interleave":
+            while self._il is not None:          # whatever the main branch's ticks did not reach
+                self._tick()
+        elif order != "done":
+            with torch.cuda.stream(self.ed_side):
+                self.g_ed_branch_side()
+
+    def dg_fork_rest(self):
+        """Everything behind the 2B-row generator pass as ONE graph whose ROOT is the fork: the emotion branch on the side
+        stream beside the critic step + critic pass, the join, the generator's backward and update (flow "fork2": two graphs
+        per batch, dg_forward_rng + this)."""
+        cur = torch.cuda.current_stream()
+        self.ed_side.wait_stream(cur)
+        self._fork_branches()
+        cur.wait_stream(self.ed_side)
         self.g_critic_back()
         self.g_backward_b()
         self.g_update()
@@ -1080,6 +1129,11 @@ class GanEngine:
         find free registers and wave slots at once instead of waiting for 15-50-us workgroups to retire.  The branch has the
         slack: it is needed only where the generator's backward starts.  Measured (cfg2, same box, alternating):
         0.913 -> 0.895 ms per step."""
+        self._require_fold()
+        if self._chain_ed:
+            for _ in self._ed_steps(self.ed_side_lds_pad, self.ed_side_lds_pad_bwd):
+                pass
+            return
         with ops.conv_lds_pad(self.ed_side_lds_pad):
             self.g_ed_branch()
 
@@ -1095,13 +1149,18 @@ class GanEngine:
         self._ed_bwd(self.dnotes if self.ed_mode == "notes" else None)
 
     def _ed_branch_chain(self):
+        for _ in self._ed_steps(0):
+            pass
+
+    def _ed_steps(self, lds_pad: int, lds_pad_bwd: Optional[int] = None):
         """g_ed_branch with the classifier's tail -- pooling, project, MLP, head, cross-entropy and every data-gradient back
         to the pooled features (ed_model.py:61,86-95,147-165) -- as ONE row-chain launch between the convolutions' forward
         and their data-gradients (was: 10 launches of ~5 us).  The loss scalar (the mean of the per-sample terms) rides in
-        the pooling-backward launch."""
+        the pooling-backward launch.  A GENERATOR that yields after every launch, so that the forked step graph can capture
+        the branch's launches INTERLEAVED with the main branch's (dg_fork_step_rng); lds_pad: the convolutions' occupancy
+        cap when the branch runs beside the critical path (g_ed_branch_side)."""
         P = self.ED.p
         notes, bf16 = self.ed_mode == "notes", self.ed_dtype == "bf16"
-        last = len(self.ed_chans) - 1
         ch = ops.Chain(self.B)
         if notes:
             x = self.notes
@@ -1111,11 +1170,14 @@ class GanEngine:
                     ops.conv_s1_bf16(x, self.ed_wb_f[i], self.ed_a[i], scale=self.ed_scale[i], shift=self.ed_shift[i],
                                      zout=self.ed_z[i], act=ACT_GELU)
                 else:
-                    ops.conv_gather(x, self.ed_wt[i], self.ed_a[i], co, k, 1, k, co * k, scale=self.ed_scale[i],
-                                    shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+                    with ops.conv_lds_pad(lds_pad):
+                        ops.conv_gather(x, self.ed_wt[i], self.ed_a[i], co, k, 1, k, co * k, scale=self.ed_scale[i],
+                                        shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+                yield
                 x = self.ed_a[i]
             if bf16:
                 ops.meanT_fwd_bf16(x, self.ed_pool)
+                yield
                 ch.load(0, self.ed_pool)
             else:
                 ch.mean_t(0, x, out=self.ed_pool)
@@ -1142,15 +1204,45 @@ class GanEngine:
         if not notes:
             ch.linear_dgrad(cur, nxt(cur), w, out=self.ed_dfeat)
             ch.launch()
+            yield
             ops.mean_scaled(self.ed_loss_rows, self.emo, 1.0)
+            yield
             return
         ch.linear_dgrad(cur, nxt(cur), w, out=self.ed_dproj)
         cur = nxt(cur)
         ch.linear_dgrad(cur, nxt(cur), P["encoder.project.weight"], out=self.ed_dpool)
         ch.launch()
+        yield
         if bf16:
             ops.mean_scaled(self.ed_loss_rows, self.emo, 1.0)
-        self._ed_bwd_convs(self.dnotes, mean=None if bf16 else (self.ed_loss_rows, self.emo, 1.0))
+            yield
+        yield from self._ed_bwd_convs_steps(self.dnotes, None if bf16 else (self.ed_loss_rows, self.emo, 1.0),
+                                            lds_pad if lds_pad_bwd is None else lds_pad_bwd)
+
+    def _ed_bwd_convs_steps(self, dnotes: Tensor, mean, lds_pad: int):
+        """_ed_bwd_convs, one launch per step (see _ed_steps)."""
+        P = self.ED.p
+        last = len(self.ed_chans) - 1
+        if self.ed_dtype == "bf16":
+            ops.meanT_bwd_bf16(self.ed_dpool, self.ed_dz[last], self.ed_z[last], ACT_GELU, self.ed_scale[last])
+            yield
+            for i in range(last, 0, -1):
+                ops.conv_s1_bf16(self.ed_dz[i], self.ed_wb_d[i], self.ed_dz[i - 1], gref=self.ed_z[i - 1], gact=ACT_GELU,
+                                 gscale=self.ed_scale[i - 1])
+                yield
+            ops.conv_s1_bf16(self.ed_dz[0], self.ed_wb_d[0], dnotes)   # fp32 out: the generator's gradient stays fp32
+            yield
+            return
+        ops.meanT_bwd(self.ed_dpool, self.ed_dz[last], gref=self.ed_z[last], gact=ACT_GELU, gscale=self.ed_scale[last], mean=mean)
+        yield
+        for i in range(last, 0, -1):
+            with ops.conv_lds_pad(lds_pad):
+                ops.conv1d_dgrad(self.ed_dz[i], P[f"encoder.conv.{i}.net.0.weight"], self.ed_dz[i - 1], 1,
+                                 gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1])
+            yield
+        with ops.conv_lds_pad(lds_pad):
+            ops.conv1d_dgrad(self.ed_dz[0], P["encoder.conv.0.net.0.weight"], dnotes, 1)
+        yield
 
     def g_critic_chain(self):
         """Critic forward + input gradient on the generated batch (with the UPDATED critic), added to the emotion
@@ -1313,6 +1405,11 @@ class GanEngine:
         # applies, so it is tracked here by sub-step name.
         fp_upd = {"d_update": self.D, "g_update": self.GE, "d_update_g_critic_chain": self.D,
                   "d_step_g_critic_front": self.D, "g_finish": self.GE, "d_update_g_critic_front": self.D}.get(name)
+        if name == "dg_fork_rest":          # both updates inside, both states advanced by dg_forward_rng's draw
+            try:
+                return self._run_graph(name, fn)
+            finally:
+                self.D.ticked = self.GE.ticked = False
         key = name + (f"#{fp_upd.ticked}" if fp_upd is not None and fp_upd.ticked else "")
         try:
             return self._run_graph(key, fn)

@@ -1302,27 +1302,33 @@ def vae_loss(recon, x, mu, logvar, beta, out, drecon=None, dmu=None, dlv=None):
 # hipGraph capture + events
 # ---------------------------------------------------------------------------------------
 class Graph:
-    """hipGraph captured from whatever is enqueued on PyTorch's current stream between
-    begin() and end()."""
+    """hipGraph captured from whatever is enqueued on PyTorch's current stream between begin() and end(), instantiated
+    `execs` times (MELO_GRAPH_EXECS, default 1): launch() goes round the executables.  (Measured: alternating between two or
+    three executables of the forked step graph is SLOWER than replaying one -- 0.879 / 0.897 / 0.906 ms per step -- so the
+    default stays 1; the knob remains for experiments.)"""
 
-    def __init__(self):
-        self.handle = C.c_void_p()
+    def __init__(self, execs: Optional[int] = None):
+        import os
+        self.n = max(1, min(8, int(execs if execs is not None else os.environ.get("MELO_GRAPH_EXECS", "1"))))
+        self.handles = (C.c_void_p * self.n)()
+        self._next = 0
 
     def begin(self):
-        # (Data-parallel runs capture every graph before their first collective -- DataParallel.prepare(): torch's
-        # process-group watchdog polls collective events, which HIP refuses on a capturing stream.)
         L.check(L.load().mg_graph_begin(_stream()), "mg_graph_begin")
 
     def end(self):
-        L.check(L.load().mg_graph_end(_stream(), C.byref(self.handle)), "mg_graph_end")
+        L.check(L.load().mg_graph_end_n(_stream(), self.handles, self.n), "mg_graph_end_n")
 
     def launch(self):
-        L.check(L.load().mg_graph_launch(self.handle, _stream()), "mg_graph_launch")
+        h = self.handles[self._next]
+        self._next = (self._next + 1) % self.n
+        L.check(L.load().mg_graph_launch(h, _stream()), "mg_graph_launch")
 
     def __del__(self):
         try:
-            if self.handle:
-                L.load().mg_graph_destroy(self.handle)
+            for h in self.handles:
+                if h:
+                    L.load().mg_graph_destroy(h)
         except Exception:
             pass
 

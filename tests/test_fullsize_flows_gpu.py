@@ -184,30 +184,37 @@ def test_side_stream_flows_full_size_match_oracle(flow):
         assert float(upd.abs().max()) <= 1.001 * eng.lr_g, k
 
 
-def test_production_graphs_full_size_equal_eager_and_each_other():
-    """dg_step_rng replayed == eager, and the split flow's four graphs == the one graph, bit for bit, at cfg2."""
+def test_production_graphs_full_size_equal_eager_and_each_other(monkeypatch):
+    """dg_step_rng replayed == eager, and the default flow (the forked graph: emotion branch on the side stream) and the
+    split flow's four graphs == the one graph, bit for bit, at cfg2."""
     import melo_gan_amd  # noqa: F401
     from melo_gan_amd.gan.engine import GanEngine
     from melo_gan_amd.gan.dp import DataParallel
     cfg, ed_cfg = O.default_gan_cfg(B, T, C), O.default_ed_cfg(C)
     S = O.build_gan_state(cfg, ed_cfg, "weights_init", seed=3)
     batch = O.synthetic_batch(B, T, C, cfg["LATENT_DIM"], 6, 42)
-    engs = [GanEngine(cfg, ed_cfg, "cuda", B) for _ in range(3)]
+    engs = [GanEngine(cfg, ed_cfg, "cuda", B) for _ in range(4)]
     for e in engs:
         e.load_state(S.PE, S.PG, S.BG, S.PD, S.PED, S.BED)
         e.seed(77)
-    e_eager, e_graph, e_split = engs
-    dp = DataParallel(e_split, 1, None)
+    e_eager, e_graph, e_fork, e_split = engs
+    dp_fork = DataParallel(e_fork, 1, None)
+    monkeypatch.setenv("MELO_ED_FLOW", "split")
+    dp_split = DataParallel(e_split, 1, None)
+    monkeypatch.delenv("MELO_ED_FLOW")
+    assert dp_fork._ed_flow == "ingraph" and dp_split._ed_flow == "split"
     with torch.cuda.stream(e_graph.stream):
         for e in engs:
             e.set_batch(*(t.cuda() for t in batch))
         for _ in range(4):
             e_eager.run("dg_step_rng", False)
             e_graph.run("dg_step_rng", True)
-            dp.step(True)
+            dp_fork.step(True)
+            dp_split.step(True)
         torch.cuda.synchronize()
+    assert "dg_fork_step_rng" in e_fork._graphs                          # the forked graph ran
     assert any(k.startswith("g_finish") for k in e_split._graphs)        # the split flow ran
-    for o in (e_graph, e_split):
+    for o in (e_graph, e_fork, e_split):
         assert torch.equal(e_eager.D.data, o.D.data) and torch.equal(e_eager.GE.data, o.GE.data)
         assert torch.equal(e_eager.notes, o.notes) and torch.equal(e_eager.loss_d_out, o.loss_d_out)
     assert torch.isfinite(e_eager.GE.data).all() and torch.isfinite(e_eager.loss_d_out).all()

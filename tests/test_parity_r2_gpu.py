@@ -195,7 +195,7 @@ def test_batch1_generation_matches_reference(name):
     with torch.cuda.stream(eng.stream):
         gr = ops.Graph()
         gr.begin()
-        eng._e_fwd(train=False)
+        eng._e_fwd(train=False, gin=True)          # as generate() does: the chain launch also assembles the generator input
         eng._g_fwd(eng.notes, train=False)
         gr.end()
         eng.notes.zero_()
