@@ -987,13 +987,11 @@ class GanEngine:
         engine takes the split flow (0.58 ms of host time for 0.926) instead."""
         if self.ed_side is None:
             return self.dg_step_rng()
+        cur = torch.cuda.current_stream()
         if draw:                                      # draw=False: the randoms were injected (parity tests)
             self.draw_randoms_both()
         self.dg_forward()
-        cur = torch.cuda.current_stream()
         self.ed_side.wait_stream(cur)                 # fork
-        # capture order of the two branches: the one captured second starts ~170 us after the fork (kernel trace); the main
-        # branch first measured 0.866 ms per step, the emotion branch first 0.881 (MELO_FORK_ORDER, round 3)
         self._fork_branches()
         cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
         self.g_critic_back()
@@ -1001,11 +999,15 @@ class GanEngine:
         self.g_update()
 
     def _fork_branches(self):
-        """The two parallel branches between fork and join.  A forked hipGraph is fed to the GPU node by node in CAPTURE order
-        at ~12 us of host time per node (kernel trace: the branch captured second started 170 us after the fork and the
-        other then waited 190 us for it at the join) -- REGARDLESS of the capture order: interleaving the two branches' launches
-        in the capture (MELO_FORK_ORDER=interleave) measured the same as main_first (0.866 ms), ed_first 0.881: the runtime
-        feeds the origin stream's chain first.  Default main_first."""
+        """The two parallel branches between fork and join.  What the runtime does with a forked hipGraph (kernel traces,
+        round 3): it assigns the branches to queues of its own, and the emotion branch's first kernel starts 150-200 us after
+        the fork node has finished WHATEVER the capture looks like -- main branch first (0.866 ms per step), the branches'
+        launches interleaved (MELO_FORK_ORDER=interleave: 0.866), the emotion branch on the capturing stream and everything
+        else on the side stream (0.868), a side-stream node at the graph's root (0.883), two alternating executables
+        (0.897); only the emotion branch captured first is different, and worse (0.881).  hipGraphLaunch of the forked graph
+        also costs the host 0.74 ms per step (0.10 for the split flow's four linear graphs) and the host does not get
+        ahead of the GPU.  The main branch then waits ~180 us at the join; the four linear graphs of the split flow start
+        both branches at once but pay three graph boundaries (0.886).  Default: main_first."""
         order = os.environ.get("MELO_FORK_ORDER", "main_first")
         if order == "ed_first" or (order == "interleave" and not self._chain_ed):
             with torch.cuda.stream(self.ed_side):
