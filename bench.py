@@ -39,8 +39,8 @@ B_PER_GPU, T, C = 64, 256, 128
 DOMINANT = ("conv_wgemm_kernel<1,3,false,true,1,1>", "conv_wgemm_kernel<1,3,false,false,1,1>")
 DOMINANT_NAME = "conv_wgemm_kernel<1,3,false,{true|false},1,1>"
 # second MFMA-bound family, reported beside it: the stride-2 five-tap window GEMMs of the critic and the generator
-CONV16 = ("conv16_kernel<false,1>", "conv16_kernel<false,2>", "conv16_kernel<true,1>", "conv16_kernel<true,2>")
-CONV16_NAME = "conv16_kernel<{false|true},{1|2}>"
+CONV16 = tuple("conv16_kernel<%s,%d,%s>" % (a, b, c) for a in ("false", "true") for b in (1, 2) for c in ("false", "true"))
+CONV16_NAME = "conv16_kernel<{false|true},{1|2},{false|true}>"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
 # conv+linear FLOPs per sample of one (1D+1G) step at cfg2 as the reference executes it
 MFLOP_PER_SAMPLE = 889.6
@@ -110,6 +110,70 @@ def time_dominant(ops, records, reps):
                 raise RuntimeError(f"replayed launch failed: rc={rc}")
     torch.cuda.synchronize()
     return sum(a.elapsed_ms(b) for a, b in pairs)
+
+
+class EventHook:
+    """Brackets every launch of the selected kernel symbols with a pair of HIP events on the launch stream (the in-step leg)."""
+
+    def __init__(self, ops, symbols):
+        self.ops, self.symbols, self.pairs = ops, set(symbols), []
+
+    def __call__(self, symbol, flops, launch=None):
+        hook = self
+
+        class Ctx:
+            def __enter__(self_c):
+                if symbol in hook.symbols:
+                    self_c.a, self_c.b = hook.ops.Event(), hook.ops.Event()
+                    self_c.a.record()
+                return self_c
+
+            def __exit__(self_c, *a):
+                if symbol in hook.symbols:
+                    self_c.b.record()
+                    hook.pairs.append((symbol, flops, self_c.a, self_c.b))
+                return False
+        return Ctx()
+
+
+def time_in_step(ops, eng, symbols, reps):
+    """The selected kernels' durations INSIDE the production step: `reps` eager runs of the forked step (emotion branch on
+    the side stream beside the critic step, as the replayed graph has it), every selected launch between its own event pair on
+    the stream it is launched on.  Returns (total ms, total flops, launches).  Eager launches leave the GPU a little less
+    contended than the graph replay does (host launch latency between kernels); rocprofv3's per-kernel average over the
+    replayed graphs is in profiles/ (tools/make_profiles.sh)."""
+    hook = EventHook(ops, symbols)
+    run = eng.dg_fork_step_rng if eng.ed_side is not None else eng.dg_step_rng
+    run()                                        # warm
+    torch.cuda.synchronize()
+    ops.set_launch_hook(hook)
+    try:
+        for _ in range(reps):
+            run()
+            eng.D.ticked = eng.GE.ticked = False
+        torch.cuda.synchronize()
+    finally:
+        ops.set_launch_hook(None)
+    ms = sum(a.elapsed_ms(b) for _, _, a, b in hook.pairs)
+    return ms, sum(f for _, f, _, _ in hook.pairs), len(hook.pairs)
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC measurement (profiles/rNN_traffic_dominant_
+    kernel.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied -- tools/pmc_traffic.py).
+    The counters cannot be read from inside this process, so the line carries the committed figure and says where it is from."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_dominant_kernel.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return float(d["traffic_bytes_per_launch"]), (f"profiles/{os.path.basename(files[-1])}: {d.get('launches', '?')} launches, "
+                                                       "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, "
+                                                       "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024")
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable {files[-1]}: {e}"
 
 
 def host_cpu():
@@ -443,12 +507,38 @@ def main():
                 # measured figure lives under profiles/ with the command that produced it
                 return dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, kernel=name,
+                            how="one dispatch at a time (recorded launches replayed, HIP event pair each)",
                             launches=launches, launches_per_step=len(recs), avg_us=round(1e3 * ms / launches, 2),
                             avg_gflop_per_launch=round(flops / launches / 1e9, 3))
             roof = leg(DOMINANT, DOMINANT_NAME)
-            if roof is not None:
-                roof["traffic_measured_in"] = "profiles/r02_traffic_dominant_kernel.json (separate rocprofv3 --pmc passes)"
             roof2 = leg(CONV16, CONV16_NAME)
+            # the same kernels INSIDE the step (two streams, as replayed): frac_in_step is the figure to hold against the
+            # rocprofv3 per-kernel average of profiles/; `frac` / `achieved` stay the one-dispatch-at-a-time measurement
+            keep = (eng.coll, eng.p2_world, eng.world_size)
+            eng.coll, eng.p2_world = None, 0
+            try:
+                for r_, syms in ((roof, DOMINANT), (roof2, CONV16)):
+                    if r_ is None:
+                        continue
+                    ms_i, fl_i, n_i = time_in_step(ops, eng, syms, max(4, args.profile_steps // 2))
+                    r_["in_step"] = {"achieved": round(fl_i / (ms_i * 1e-3) / 1e12, 2), "frac": round(fl_i / (ms_i * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "avg_us": round(1e3 * ms_i / n_i, 2), "launches": n_i,
+                                     "how": "eager forked step (emotion branch on the side stream), HIP event pair per launch"}
+            finally:
+                eng.coll, eng.p2_world, eng.world_size = keep
+            if roof is not None:
+                tb, prov = measured_traffic()
+                roof["traffic"] = tb
+                roof["traffic_provenance"] = prov
+                # algorithmic bytes per launch, averaged over the six launches of a step (ED conv1-3: forward reads x and w,
+                # writes the activation AND the pre-activation; data-gradient reads dy, the saved pre-activation and w, writes dx)
+                algo = 0.0
+                for ci, co in ((64, 128), (128, 256), (256, 256)):
+                    xb, yb, wb = 4.0 * B_PER_GPU * T * ci, 4.0 * B_PER_GPU * T * co, 4.0 * ci * co * 3
+                    algo += (xb + 2 * yb + wb) + (yb + 2 * xb + wb)
+                roof["traffic_algorithmic"] = round(algo / 6, 0)
+                if tb:
+                    roof["traffic_over_algorithmic"] = round(tb / (algo / 6), 3)
         if rank == 0 and args.launch_flops:
             tally = {}
 
@@ -463,6 +553,9 @@ def main():
             ops.set_launch_hook(None)
             with open(args.launch_flops, "w") as f:
                 json.dump(tally, f, indent=1)
+        # launches per step = kernel nodes of the step's graph(s) as captured
+        step_graphs = [v for k, v in eng._graphs.items() if k.split("#")[0] in ("dg_fork_step_rng", "dg_step_rng") and not isinstance(v, str)]
+        launches_per_step = step_graphs[0][0].kernel_nodes if step_graphs else None
         loss_d, adv, emo = eng.loss_d_out[0].item(), eng.adv.item(), eng.emo.item()
 
     # ---- secondary configuration beside the fp32 headline (BASELINE.json configs[1] names bf16): the same step with the
@@ -517,6 +610,11 @@ def main():
                                    "(1 critic update incl. gradient penalty + 1 generator update)",
                        "global_batch": world * B_PER_GPU, "T": T, "C": C, "parallelism": f"dp{world}",
                        "graph": use_graph, "step_gflop": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3, 2),
+                       # the reference's step computes the critic's weight gradients in the generator step as well and
+                       # throws them away (train_gan.py:225): 1.69 GF per step that this build does not execute
+                       "step_gflop_executed": round(MFLOP_PER_SAMPLE * B_PER_GPU / 1e3 - 1.69, 2),
+                       "step_tflops_executed": round((MFLOP_PER_SAMPLE * B_PER_GPU / 1e3 - 1.69) / (1e3 * el / args.steps), 2),
+                       "launches_per_step": launches_per_step,
                        "dp_mode": dp.mode if dp.active else None},
             "host_ms_per_step": round(1e3 * host_el / args.steps, 4),
             "event_timing": event_timing, "roofline": roof, "roofline_stride2_family": roof2, "cpu_baseline": cpu,

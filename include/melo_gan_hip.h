@@ -491,6 +491,8 @@ int mg_graph_begin(mg_stream_t stream);
 int mg_graph_end(mg_stream_t stream, void** graph_exec_out);
 /* mg_graph_end with the capture instantiated n (1..8) times (launches may then alternate between the executables). */
 int mg_graph_end_n(mg_stream_t stream, void** graph_execs_out, int n);
+/* kernel nodes of the graph the calling thread captured last (-1: unknown): the launches one replay stands for */
+int mg_graph_last_kernel_nodes(void);
 int mg_graph_launch(void* graph_exec, mg_stream_t stream);
 int mg_graph_destroy(void* graph_exec);
 

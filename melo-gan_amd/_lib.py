@@ -138,6 +138,7 @@ SIGNATURES = {
     "mg_graph_begin": (i32, [vp]),
     "mg_graph_end": (i32, [vp, C.POINTER(vp)]),
     "mg_graph_end_n": (i32, [vp, C.POINTER(vp), i32]),
+    "mg_graph_last_kernel_nodes": (i32, []),
     "mg_graph_launch": (i32, [vp, vp]),
     "mg_graph_destroy": (i32, [vp]),
     "mg_event_create": (i32, [C.POINTER(vp)]),

@@ -69,7 +69,9 @@ constexpr int WSLAB = 4 * K5 * WPLANE;  // 20 planes = 10 KB per chunk
 constexpr int MAXX = 3;                 // window float4 slots per thread (<= 192 window rows per tile)
 constexpr int NWU = 3;                  // weight float4 slots per thread (640 per chunk over 256 threads)
 
-template <bool TR2, int RT>
+// RID: the launch carries a rider (statistics, temporal mean, permuted output order, interpolate); the plain instantiation
+// has none of that code (the riders cost ~0.8 us per launch in registers and index arithmetic even when unused)
+template <bool TR2, int RT, bool RID>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     constexpr int BM = 32 * RT;
     constexpr int SX = PitchOf<TR2>::value;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     const float scale = E.scale ? E.scale[n] : 1.f, shift = E.scale ? E.shift[n] : 0.f;
     const float gscale = E.gscale ? E.gscale[n] : 1.f;
     float st1 = 0.f, cnt = 0.f;
-    const bool want_stats = p.part || p.pool;
+    const bool want_stats = RID && (p.part || p.pool);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -266,9 +268,9 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
                 const int b = b0 + seg, t = t0 + tl;
                 const int tout = TR2 ? 2 * t + ph : t;
                 di[r] = (unsigned)((b * p.Tout + tout) * p.N + n);
-                yi[r] = (unsigned)(b * (int)p.ybs + (p.y_perm ? n * p.Tout + tout : tout * p.N + n));
+                yi[r] = (unsigned)(b * (int)p.ybs + ((RID && p.y_perm) ? n * p.Tout + tout : tout * p.N + n));
                 ok[r] = b < p.B && t < p.Tm && tout < p.Tout;
-                mixrow[r] = ok[r] && b < p.mix_rows;
+                mixrow[r] = RID && ok[r] && b < p.mix_rows;
                 brow[r] = mixrow[r] ? b : 0;
             }
 #pragma unroll
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (ok[r]) p.y[yi[r]] = a[r];
-            if (p.mix_out) {
+            if (RID && p.mix_out) {
                 float rv[4], al[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -397,7 +399,7 @@ __global__ void wq_relayout_kernel(const float* __restrict__ w, float* __restric
     wq[i] = w[(long)n * sn + (long)(4 * q + e) * sc + k];
 }
 
-template <bool TR2, int RT>
+template <bool TR2, int RT, bool RID>
 int launch16(Conv16P p, hipStream_t stream) {
     constexpr int BM = 32 * RT;
     constexpr int SX = PitchOf<TR2>::value;
@@ -413,7 +415,7 @@ int launch16(Conv16P p, hipStream_t stream) {
     const int R = (TT - 1) * SA + NR;
     if (TB * R * 4 > 256 * MAXX) return MG_EUNSUP;        // too many window rows for the staging plan (tiny Tm)
     const size_t lds = 2 * ((size_t)TB * R * SX + WSLAB) * sizeof(float) + 256 * 4 * sizeof(float);
-    auto kernel = &conv16_kernel<TR2, RT>;
+    auto kernel = &conv16_kernel<TR2, RT, RID>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -560,8 +562,14 @@ static int conv16_launch(const float* x, const float* wq, float* y, int B, int T
     hipStream_t s = (hipStream_t)stream;
     const int rt = pick_rt((long)B * Tm, N);
     int rc;
-    if (transposed) rc = rt == 2 ? launch16<true, 2>(p, s) : launch16<true, 1>(p, s);
-    else rc = rt == 2 ? launch16<false, 2>(p, s) : launch16<false, 1>(p, s);
+    const bool rid = p.part || p.pool || p.y_perm || p.mix_out;
+    if (rid) {
+        if (transposed) rc = rt == 2 ? launch16<true, 2, true>(p, s) : launch16<true, 1, true>(p, s);
+        else rc = rt == 2 ? launch16<false, 2, true>(p, s) : launch16<false, 1, true>(p, s);
+    } else {
+        if (transposed) rc = rt == 2 ? launch16<true, 2, false>(p, s) : launch16<true, 1, false>(p, s);
+        else rc = rt == 2 ? launch16<false, 2, false>(p, s) : launch16<false, 1, false>(p, s);
+    }
     if (rc == MG_EUNSUP) mg_set_error("mg_conv16: Tm=%d needs more window rows than the staging plan holds", Tm);
     return rc;
 }

@@ -1,6 +1,7 @@
 // Error string, hipGraph capture and event timing for libmelogan_hip.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -36,10 +37,31 @@ int mg_graph_end(mg_stream_t stream, void** graph_exec_out) {
 }
 // The same capture instantiated `n` times (an experiment knob: alternating executables of the step graph measured slower
 // than replaying one, melo-gan_amd/ops.py::Graph).
+static thread_local int g_last_kernel_nodes = -1;
+int mg_graph_last_kernel_nodes(void) { return g_last_kernel_nodes; }
+
+static void count_kernel_nodes(hipGraph_t graph) {
+    g_last_kernel_nodes = -1;
+    size_t n = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess || n == 0 || n > 65536) return;
+    hipGraphNode_t* nodes = (hipGraphNode_t*)malloc(n * sizeof(hipGraphNode_t));
+    if (!nodes) return;
+    if (hipGraphGetNodes(graph, nodes, &n) == hipSuccess) {
+        int k = 0;
+        for (size_t i = 0; i < n; ++i) {
+            hipGraphNodeType t;
+            if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++k;
+        }
+        g_last_kernel_nodes = k;
+    }
+    free(nodes);
+}
+
 int mg_graph_end_n(mg_stream_t stream, void** graph_execs_out, int n) {
     MG_CHECK_ARG(graph_execs_out != nullptr && n >= 1 && n <= 8, "mg_graph_end_n: 1..8 executables");
     hipGraph_t graph = nullptr;
     MG_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+    count_kernel_nodes(graph);
     for (int i = 0; i < n; ++i) {
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

@@ -316,7 +316,8 @@ def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool
     def launch():
         return lib.mg_conv16_ex(_p(x), _p(wq), _p(y), B, Tin, Cin, N, 1 if transposed else 0, Tout, Tin * Cin, Ty * N, C.byref(e),
                                 C.byref(ex), _stream())
-    sym = lambda: "conv16_kernel<%s,%d>" % ("true" if transposed else "false", _conv16_plan(B, Tin, N, transposed)[2] // 32)  # noqa: E731
+    rid = "true" if (stats is not None or pool is not None or perm or mix is not None) else "false"
+    sym = lambda: "conv16_kernel<%s,%d,%s>" % ("true" if transposed else "false", _conv16_plan(B, Tin, N, transposed)[2] // 32, rid)  # noqa: E731
     with _observe(sym, 2.0 * B * (Tin if transposed else Tout) * N * Cin * 5, launch):
         rc = launch()
     L.check(rc, "mg_conv16")
@@ -1318,6 +1319,7 @@ class Graph:
 
     def end(self):
         L.check(L.load().mg_graph_end_n(_stream(), self.handles, self.n), "mg_graph_end_n")
+        self.kernel_nodes = L.load().mg_graph_last_kernel_nodes()      # launches one replay stands for
 
     def launch(self):
         h = self.handles[self._next]
