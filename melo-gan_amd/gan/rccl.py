@@ -79,7 +79,18 @@ class RcclComm:
         u = _UniqueId()
         C.memmove(C.byref(u), uid, _UID_BYTES)
         self._comm = C.c_void_p()
-        _check(_load().ncclCommInitRank(C.byref(self._comm), self.world, u, self.rank), "ncclCommInitRank")
+        # RCCL prints a version banner on STDOUT when a communicator is created; bench.py's stdout is one JSON line: send
+        # the library's output to stderr for the duration of the call
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = _load().ncclCommInitRank(C.byref(self._comm), self.world, u, self.rank)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        _check(rc, "ncclCommInitRank")
 
     @classmethod
     def from_process_group(cls, dist, group=None) -> "RcclComm":

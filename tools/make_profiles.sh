@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the measurement artefacts quoted in DESIGN.md on a GPU box, into gpurun_out/profiles_$1/ (copy the ones to be
-# judged into profiles/ with the round prefix).  One gpurun call:  gpurun --timeout 1100 -- 'bash tools/make_profiles.sh r02'
+# judged into profiles/ with the round prefix).  One gpurun call:  gpurun --timeout 1100 -- 'bash tools/make_profiles.sh r03'
 # PMC passes run alone (--pmc with --kernel-trace only), the program directly after `--` (no wrapper).
 set -e -o pipefail
 TAG=${1:-run}
@@ -19,4 +19,8 @@ python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch/f_counter_collection.csv $OUT/pmc
 echo "[6/7] layer benches"; python3 $R/tools/layer_bench.py > $OUT/layer_bench.txt 2>/dev/null; python3 $R/tools/conv16_bench.py > $OUT/conv16_bench.txt 2>/dev/null
 echo "[7/7] other workloads"; python3 $R/tools/ref_shape_bench.py > $OUT/other_workloads.txt 2>/dev/null
 for w in ae gen1 ed; do python3 $R/bench.py --workload $w --no-cpu-baseline >> $OUT/other_workloads.txt 2>/dev/null; done
+ls -la $OUT
+echo "[8/8] chains + timeline"; (cd $R/tools && python3 chain_bench.py > $OUT/chain_bench.txt 2>/dev/null; python3 ed_pad_bench.py > $OUT/ed_pad_bench.txt 2>/dev/null)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -o s -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --profile-steps 0 > /dev/null 2>&1
+python3 $R/tools/timeline.py $OUT/tl/s_kernel_trace.csv 30 > $OUT/step_timeline.txt; rm -rf $OUT/tl
 ls -la $OUT
