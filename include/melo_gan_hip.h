@@ -193,6 +193,9 @@ typedef struct mg_chain_op {
 int mg_row_chain(const mg_chain_op* ops, int n_ops, int rows, mg_stream_t stream);
 /* out[0] = scale * mean(src[0..n)) (one block): the loss scalar behind a chain's per-row cross-entropy terms */
 int mg_mean_scaled(const float* src, float* out, int n, float scale, mg_stream_t stream);
+/* dst[0] = the device's constant-rate clock (wall_clock64, 100 MHz) when the node runs: a time stamp inside a captured graph
+ * (measurement only: tools/step_stamps.py) */
+int mg_stamp(unsigned long long* dst, mg_stream_t stream);
 
 /* ---- skinny GEMM for nn.Linear forward / data-gradient with few rows (M = batch) ----
  *   y[M,N] = EPI( x[M,K] @ W^T ),  W(n,c) = w[n*w_sn + c*w_sc], one of the strides must be 1:

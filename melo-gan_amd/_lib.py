@@ -110,6 +110,7 @@ SIGNATURES = {
     "mg_meanT_bwd_mean": (i32, [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, i32, f32, vp]),
     "mg_row_chain": (i32, [vp, i32, i32, vp]),
     "mg_mean_scaled": (i32, [vp, vp, i32, f32, vp]),
+    "mg_stamp": (i32, [vp, vp]),
     "mg_gp_interp": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "mg_gp_penalty": (i32, [vp, vp, vp, vp, f32, i32, i64, vp]),
     "mg_wgan_d_loss": (i32, [vp, vp, f32, vp, i32, vp]),

@@ -1376,6 +1376,17 @@ int mg_mean_scaled(const float* src, float* out, int n, float scale, mg_stream_t
     return MG_OK;
 }
 
+// One lane writes the constant-rate (100 MHz) device clock: a time stamp INSIDE a captured graph, where the profiler's view of
+// a forked graph is not to be trusted (tools/step_stamps.py).
+__global__ void stamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+
+int mg_stamp(unsigned long long* dst, mg_stream_t stream) {
+    MG_CHECK_ARG(dst, "mg_stamp: bad args");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ST, dst);
+    MG_CHECK_LAUNCH("stamp");
+    return MG_OK;
+}
+
 int mg_fill(float* x, float v, long n, mg_stream_t stream) {
     MG_CHECK_ARG(x && n >= 0, "mg_fill: bad args");
     if (n == 0) return MG_OK;

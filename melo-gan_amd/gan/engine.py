@@ -315,6 +315,7 @@ class GanEngine:
         self.stream = torch.cuda.Stream(device=d)
         # side stream of the fused step's emotion branch (dg_step_rng); MELO_ED_SIDE=0: everything on one stream
         self.ed_side = torch.cuda.Stream(device=d) if os.environ.get("MELO_ED_SIDE", "1") == "1" else None
+        self._tail_fork = False         # set by the forked step around g_backward_b
         self.ed_side_lds_pad = int(os.environ.get("MELO_ED_LDS_PAD", "42000"))      # g_ed_branch_side
         # its data-gradient convolutions: the same cap.  (In the forked-graph flow they mostly run after the main branch has
         # reached the join, yet lifting the cap for them measured SLOWER: 0.867 -> 0.882 ms per step; alone on the chip a
@@ -626,9 +627,19 @@ class GanEngine:
                      key, self.rng_step, tick_state=fp.state, betas=self.betas)
         fp.ticked = True
 
+    def _stamp(self, i: int):
+        """MELO_STAMPS=1: a one-lane node writing the device clock into stamps[i] (tools/step_stamps.py): 0 step start, 1 fork
+        (generator pass done), 2 / 3 emotion branch first / last node, 4 main branch at the join, 5 behind the join, 6 end."""
+        if os.environ.get("MELO_STAMPS", "0") != "1":
+            return
+        if not hasattr(self, "stamps"):
+            self.stamps = torch.zeros(8, dtype=torch.int64, device=self.dev)
+        ops.stamp(self.stamps, i)
+
     def draw_randoms_both(self):
         """The fused step's draw: noise and dropout masks of BOTH halves plus alpha in one launch, which advances both
         optimisers' Adam states; the critic update advances the Philox counter."""
+        self._stamp(0)
         self._stage_bound()
         ops.rng_fill(self.noise_2, self.alpha, self.dmask_2[0], self.dmask_2[1], P_DROP, self.rng_seed, self.rng_step,
                      tick_state=self.D.state, betas=self.betas, tick_state2=self.GE.state)
@@ -964,6 +975,7 @@ class GanEngine:
         self._p2_pending, self._a_p0_gathered = bool(self.coll is not None and self.p2_world), False
         self._e_fwd(True, "both", gin=True)
         self._g_fwd(self.X0[2 * self.B:], True, "both")
+        self._stamp(1)
 
     def dg_step_rng(self):
         """Draw + critic step + generator step as ONE capturable sequence (single-GPU production path whenever a
@@ -995,7 +1007,11 @@ class GanEngine:
         self._fork_branches()
         cur.wait_stream(self.ed_side)                 # join: from here on dnotes needs the emotion branch's part
         self.g_critic_back()
-        self.g_backward_b()
+        self._tail_fork = os.environ.get("MELO_TAIL_FORK", "1") == "1"
+        try:
+            self.g_backward_b()
+        finally:
+            self._tail_fork = False
         self.g_update()
 
     def _fork_branches(self):
@@ -1132,12 +1148,14 @@ class GanEngine:
         slack: it is needed only where the generator's backward starts.  Measured (cfg2, same box, alternating):
         0.913 -> 0.895 ms per step."""
         self._require_fold()
+        self._stamp(2)
         if self._chain_ed:
             for _ in self._ed_steps(self.ed_side_lds_pad, self.ed_side_lds_pad_bwd):
                 pass
-            return
-        with ops.conv_lds_pad(self.ed_side_lds_pad):
-            self.g_ed_branch()
+        else:
+            with ops.conv_lds_pad(self.ed_side_lds_pad):
+                self.g_ed_branch()
+        self._stamp(3)
 
     def g_ed_branch(self):
         """The frozen emotion discriminator's forward, cross-entropy and input gradient on the generated batch: the only
@@ -1258,9 +1276,11 @@ class GanEngine:
         self._d_fwd(self.notes, B, self.emb, head=False)
         # adv = -mean(D(fake)) (train_gan.py:224) rides in the pooling-backward launch: s is written two launches earlier
         self._d_bwd_input(self.ds_g, B, self.emb, self.demb, with_head=True, mean=(self.s[:B], self.adv, -1.0))
+        self._stamp(4)
 
     def g_critic_back(self):
         B = self.B
+        self._stamp(5)
         PG, GG = self._gp, (lambda k: self.GE.g["G." + k])
         self._conv5s2("conv_dgrad", self.dZ1[:B], self.D, "conv.0.weight", self.dnotes, accumulate=self.ed_mode == "notes")
         # ---- generator backward: the data-gradient chain down to decoder.pre.2, then pre.2's weight gradient -- 89 % of
@@ -1305,14 +1325,27 @@ class GanEngine:
             self.coll.gather_p2(self, not self._a_p0_gathered)
             jobs.append(ops.linear_wgrad(self.a_p0_all, self.d_p2_all, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
                                          defer=True))
+        big = []                # everything whose operands g_critic_back has left behind: 95 % of this pass's gradient FLOPs
         if not self.p2_world:
-            jobs.append(ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
-                                         defer=True))
-        jobs.append(ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"), defer=True))
-        jobs.append(ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"),
-                                      defer=True))
-        jobs.append(ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"),
-                                      defer=True))
+            big.append(ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
+                                        defer=True))
+        big.append(ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"), defer=True))
+        big.append(ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"),
+                                     defer=True))
+        big.append(ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"),
+                                     defer=True))
+        tail_fork = self._tail_fork and self.ed_side is not None and self.coll is None
+        if tail_fork:
+            # the forked step graph's second fork: these gradients on the side stream BESIDE the small dependent launches
+            # below (pre.2's data-gradient, the back chain, the LayerNorm parameters), which leave the chip nearly empty
+            cur = torch.cuda.current_stream()
+            self.ed_side.wait_stream(cur)
+            with torch.cuda.stream(self.ed_side):
+                ops.wgrad_multi(big, tag="_side")
+        else:
+            # the same launches on this stream: a launch's slice plan depends on its job list, and every flow must produce
+            # the same bits (test_production_graphs_full_size_equal_eager_and_each_other)
+            ops.wgrad_multi(big, tag="_side")
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
         jobs.append(ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"), defer=True))
         jobs.append(ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"),
@@ -1344,6 +1377,8 @@ class GanEngine:
             ch.launch()
             ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
             ops.wgrad_multi(jobs)
+            if tail_fork:
+                torch.cuda.current_stream().wait_stream(self.ed_side)
             return
         ops.linear_dgrad(self.d_p0, PG("decoder.pre.0.weight"), self.d_lat)
         if self.ed_mode != "notes":
@@ -1366,6 +1401,8 @@ class GanEngine:
             ops.linear_dgrad(self.d_ez1, PE("net.1.weight"), self.d_ex0)
         ops.layernorm_bwd_params(self.d_ex0, self.e_xhat, GEg("net.0.weight"), GEg("net.0.bias"))
         ops.wgrad_multi(jobs)
+        if tail_fork:
+            torch.cuda.current_stream().wait_stream(self.ed_side)
 
     def enable_p2_gather(self, world: int):
         """Data parallelism without all-reducing decoder.pre.2.weight's gradient (16.8 of the 18.8 MB at cfg2): that
@@ -1392,6 +1429,7 @@ class GanEngine:
             self.coll.reduce_g(self)        # C3
             self._p2_pending = self._a_p0_gathered = False
         self._adam(self.GE, self.lr_g)
+        self._stamp(6)
 
     # -------------------------------------------------------------------------------------
     # graph capture / replay

@@ -562,6 +562,11 @@ def mean_scaled(src, out, scale=1.0):
     L.check(L.load().mg_mean_scaled(_p(src), _p(out), src.numel(), float(scale), _stream()), "mg_mean_scaled")
 
 
+def stamp(buf, i: int):
+    """buf[i] (int64 device tensor) = the device clock when this node runs (100 MHz ticks)."""
+    L.check(L.load().mg_stamp(buf.data_ptr() + 8 * int(i), _stream()), "mg_stamp")
+
+
 # ---------------------------------------------------------------------------------------
 # weight gradients
 # ---------------------------------------------------------------------------------------
@@ -658,8 +663,9 @@ def _wgrad_job(small, large, out, K, stride, small2=None, large2=None, bias_out=
     return (small, large, nb0, small2, large2, nb1, out, bias_out, bias_from, Ts, Tl, A, Bc, K, stride)
 
 
-def wgrad_multi(jobs):
-    """Independent weight gradients of one (K, stride), given as _wgrad_job tuples (conv1d_wgrad / convT1d_wgrad /
+def wgrad_multi(jobs, tag=""):
+    """`tag` names the slab workspace: two wgrad_multi calls that may run CONCURRENTLY (different streams) need different tags.
+    Independent weight gradients of one (K, stride), given as _wgrad_job tuples (conv1d_wgrad / convT1d_wgrad /
     linear_wgrad with defer=True return them), in ONE launch (+ one reduce launch if any of them is split over the
     batch): the small layers' gradients are each a few workgroups at the launch floor.  More than MG_MAX_WGRAD_JOBS
     jobs, or jobs of different (K, stride), go out as several launches."""
@@ -679,7 +685,7 @@ def wgrad_multi(jobs):
                 a.Ts, a.Tl, a.A, a.Bc = Ts, Tl, A, Bc
                 need += (lib.mg_wgrad_workspace_bytes(A, Bc, K, nb0 + nb1, Ts) + 255) & ~255
                 flops += 2.0 * (nb0 + nb1) * Ts * A * Bc * K
-            work = workspace(need, part[0][0].device, "wgrad_multi")
+            work = workspace(need, part[0][0].device, "wgrad_multi" + tag)
             with _observe(lambda: f"wgrad_multi_kernel<{stride},{K}>", flops):
                 rc = lib.mg_wgrad_multi(arr, len(part), K, stride, _p(work), work.numel() * work.element_size(), _stream())
             L.check(rc, "mg_wgrad_multi")
