@@ -212,6 +212,20 @@ int mg_linear(const float* x, const float* w, float* y, int M, int K, int N, int
 int mg_linear_perm(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, int w_sc,
                    const mg_epilogue* epi, int perm_L, void* work, size_t work_bytes, mg_stream_t stream);
 
+/* ---- stride-1 three-tap Conv1d (padding 1) by minimal filtering F(2,3) along time (csrc/conv_wino.hip) ----
+ * Same result as mg_conv1d_gather(K = 3, stride = 1) up to rounding (the operands are transformed: a few ulp), with 2/3 of
+ * its matrix-pipe work: four channel GEMMs per PAIR of outputs instead of six.  For the frozen emotion discriminator's
+ * conv1-3 and their input gradients (src/emotion_discriminator/ed_model.py:24-46 inside src/gan/train_gan.py:228-236).
+ *   mg_wino3_weights: wt[Cin/4][4][N][4] = the filter transform of g_k = W(n, c, flip ? 2-k : k), W(n,c,k) = w[n*w_sn + c*w_sc + k]
+ *                     (forward: w (N,Cin,3), w_sn = 3 Cin, w_sc = 3; data gradient of a Conv1d whose weight is (Cout,Cin,3):
+ *                     N = Cin, "Cin" = Cout, w_sn = 3, w_sc = 3 Cin_conv, flip = 1).  Cin % 4 == 0.
+ *   mg_conv1d_wino3:  y[b,t,n] = EPI( sum_{k,c} x[b, t+k-1, c] * g_k(n,c) ), x (B,T,Cin) and y (B,T,N) dense, 16-byte aligned;
+ *                     T even, Cin % 16 == 0, N % 64 == 0 (mg_conv1d_wino3_supported).  Honours mg_conv_set_lds_pad. */
+int mg_conv1d_wino3_supported(int B, int T, int Cin, int N);
+int mg_wino3_weights(const float* w, float* wt, int N, int Cin, long w_sn, long w_sc, int flip, mg_stream_t stream);
+int mg_conv1d_wino3(const float* x, const float* wt, float* y, int B, int T, int Cin, int N, const mg_epilogue* epi,
+                    mg_stream_t stream);
+
 /* Which instantiation of conv_wgemm_kernel<S,K,TR2,TM,TN> a call launches: TM*10+TN (22: 128x128 tile,
  * 12: 64x128, 11: 64x64).  m_rows = B*Tout (gather) or B*Tin (scatter2).  Lets a profiler label
  * launches by kernel symbol. */

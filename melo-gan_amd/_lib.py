@@ -111,6 +111,9 @@ SIGNATURES = {
     "mg_row_chain": (i32, [vp, i32, i32, vp]),
     "mg_mean_scaled": (i32, [vp, vp, i32, f32, vp]),
     "mg_stamp": (i32, [vp, vp]),
+    "mg_conv1d_wino3_supported": (i32, [i32, i32, i32, i32]),
+    "mg_wino3_weights": (i32, [vp, vp, i32, i32, i64, i64, i32, vp]),
+    "mg_conv1d_wino3": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "mg_gp_interp": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "mg_gp_penalty": (i32, [vp, vp, vp, vp, f32, i32, i64, vp]),
     "mg_wgan_d_loss": (i32, [vp, vp, f32, vp, i32, vp]),

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmelogan_hip.so")
-SOURCES = ["runtime.hip", "conv_mfma.hip", "conv16_mfma.hip", "conv_thin.hip", "conv_bf16.hip", "linear_skinny.hip", "wgrad_mfma.hip", "small_kernels.hip", "row_chain.hip"]
+SOURCES = ["runtime.hip", "conv_mfma.hip", "conv16_mfma.hip", "conv_thin.hip", "conv_bf16.hip", "conv_wino.hip", "linear_skinny.hip", "wgrad_mfma.hip", "small_kernels.hip", "row_chain.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 # conv_mfma.hip stores transposed weight quads as scalar pairs on purpose (see store_pair there)

@@ -839,6 +839,8 @@ extern "C" int mg_conv_tile_config(long m_rows, int N, int scatter2) {
     return scatter2 ? scatter_tile(m_rows, N) : gather_tile(m_rows, N);
 }
 
+long mg_conv_lds_pad_value() { return g_conv_lds_pad; }      // conv_wino.hip
+
 extern "C" int mg_conv_set_lds_pad(long bytes) {
     MG_CHECK_ARG(bytes >= 0 && bytes <= 120 * 1024, "mg_conv_set_lds_pad: 0..120 KiB");
     g_conv_lds_pad = bytes;

@@ -210,6 +210,16 @@ class GanEngine:
         # the frozen ED's conv weights re-laid once as (Cin, Cout, K): its forward then takes the window GEMM's CNK
         # weight staging (coalesced dword loads + conflict-free 16-B LDS stores), 5-7 % faster than the NCK one
         self.ed_wt = [torch.empty(ci, co, k, device=d) for (ci, co, k) in self.ed_chans]
+        # its three-tap layers by minimal filtering F(2,3) (csrc/conv_wino.hip: 2/3 of the direct form's matrix-pipe work;
+        # filter transforms made once in fold_ed): forward where the layer has >= 128 output columns, data-gradient where it
+        # has >= 128 input channels (= the gradient's columns; with 64 the launch is 128 workgroups and the direct kernel
+        # wins: tools/wino_bench.py).  MELO_ED_WINO=0: the direct window GEMMs everywhere.
+        wino = os.environ.get("MELO_ED_WINO", "1") == "1" and ed_dtype != "bf16"
+        self.ed_wino_f = [bool(wino and k == 3 and co >= 128 and ops.wino3_supported(B, T, ci, co)) for (ci, co, k) in self.ed_chans]
+        self.ed_wino_d = [bool(wino and k == 3 and ci >= 128 and ops.wino3_supported(B, T, co, ci)) for (ci, co, k) in self.ed_chans]
+        wimg = lambda on, cin, n: torch.zeros(cin // 4, 4, n, 4, device=d) if on else None  # noqa: E731
+        self.ed_wino_wf = [wimg(f, ci, co) for f, (ci, co, _) in zip(self.ed_wino_f, self.ed_chans)]     # refreshed by fold_ed
+        self.ed_wino_wd = [wimg(f, co, ci) for f, (ci, co, _) in zip(self.ed_wino_d, self.ed_chans)]
 
         # ---- static inputs ----
         # Everything the E_num / generator forward touches has 2B rows: rows [0, B) belong to the critic step's pass
@@ -368,6 +378,14 @@ class GanEngine:
             add(self.GE, "GE", nm, "dgrad", Cin, Cout, Cout * 5, 5)      # gather form: n = Cin, c = Cout
         self._wq_tab = {"D": ops.wq_table(ent["D"]) if ent["D"] else None,
                         "GE": ops.wq_table(ent["GE"]) if ent["GE"] else None}
+        # the generator's update in two ranges (forked step, g_backward_b): [0, head) = decoder.pre.2 (89 % of the bytes; no
+        # WQ copy inside), [head, n) = everything else with the table's offsets re-based
+        o, cnt = self.GE.offsets["G.decoder.pre.2.bias"]
+        self._ge_head = o + cnt if self.GE.offsets["G.decoder.pre.2.weight"][0] == 0 else 0
+        if any(e[0] < self._ge_head for e in ent["GE"]):
+            self._ge_head = 0
+        self._wq_tab["GE_rest"] = ops.wq_table([(e[0] - self._ge_head,) + tuple(e[1:]) for e in ent["GE"]]) if ent["GE"] else None
+        self._ge_head_done = False
 
     def _init_chains(self):
         """Which small per-sample layer stacks run as ONE row-chain launch (csrc/row_chain.hip) instead of a launch per
@@ -833,12 +851,34 @@ class GanEngine:
             ops.bn_fold(self.ED.p[pre + ".1.weight"], self.ED.p[pre + ".1.bias"], self.EDbuf[pre + ".1.running_mean"],
                         self.EDbuf[pre + ".1.running_var"], self.ED.p[pre + ".0.bias"], self.ed_scale[i], self.ed_shift[i], BN_EPS)
             self.ed_wt[i].copy_(self.ED.p[pre + ".0.weight"].permute(1, 0, 2))
+            ci, co, k = self.ed_chans[i]
+            if self.ed_wino_f[i]:
+                ops.wino3_weights(self.ED.p[pre + ".0.weight"], co, ci, ci * 3, 3, out=self.ed_wino_wf[i])
+            if self.ed_wino_d[i]:
+                ops.wino3_weights(self.ED.p[pre + ".0.weight"], ci, co, 3, ci * 3, flip=True, out=self.ed_wino_wd[i])
             if self.ed_dtype == "bf16":
-                ci, co, k = self.ed_chans[i]
                 w = self.ED.p[pre + ".0.weight"]                       # (co, ci, k)
                 ops.wb_relayout(w, self.ed_wb_f[i], co, ci, k, ci * k, k)
                 ops.wb_relayout(w, self.ed_wb_d[i], ci, co, k, k, ci * k, flip=True)
         self._ed_folded = True
+
+    def _ed_conv_fwd(self, i: int, x: Tensor):
+        """Layer i of the frozen encoder, fp32: Conv1d -> folded BatchNorm (z kept) -> GELU (ed_model.py:24-46)."""
+        ci, co, k = self.ed_chans[i]
+        if self.ed_wino_f[i]:
+            ops.conv_wino3(x, self.ed_wino_wf[i], self.ed_a[i], scale=self.ed_scale[i], shift=self.ed_shift[i],
+                           zout=self.ed_z[i], act=ACT_GELU)
+        else:
+            ops.conv_gather(x, self.ed_wt[i], self.ed_a[i], co, k, 1, k, co * k, scale=self.ed_scale[i],
+                            shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+
+    def _ed_conv_dgrad(self, i: int, out: Tensor):
+        """Layer i's input gradient from ed_dz[i], fp32; for i > 0 times GELU'(z) and the BatchNorm scale of layer i-1."""
+        epi = dict(gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1]) if i > 0 else {}
+        if self.ed_wino_d[i]:
+            ops.conv_wino3(self.ed_dz[i], self.ed_wino_wd[i], out, **epi)
+        else:
+            ops.conv1d_dgrad(self.ed_dz[i], self.ED.p[f"encoder.conv.{i}.net.0.weight"], out, 1, **epi)
 
     def _ed_fwd(self, notes: Tensor):
         """EmotionDiscriminator.forward in eval mode (ed_model.py:63-69,92-95,147-165)."""
@@ -855,9 +895,7 @@ class GanEngine:
         elif self.ed_mode == "notes":
             x = notes
             for i in range(len(self.ed_chans)):
-                ci, co, k = self.ed_chans[i]
-                ops.conv_gather(x, self.ed_wt[i], self.ed_a[i], co, k, 1, k, co * k, scale=self.ed_scale[i],
-                                shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+                self._ed_conv_fwd(i, x)
                 x = self.ed_a[i]
             ops.meanT_fwd(x, self.ed_pool)
             ops.linear_fwd(self.ed_pool, P["encoder.project.weight"], self.ed_proj, bias=P["encoder.project.bias"])
@@ -900,9 +938,8 @@ class GanEngine:
             return
         ops.meanT_bwd(self.ed_dpool, self.ed_dz[last], gref=self.ed_z[last], gact=ACT_GELU, gscale=self.ed_scale[last], mean=mean)
         for i in range(last, 0, -1):
-            ops.conv1d_dgrad(self.ed_dz[i], P[f"encoder.conv.{i}.net.0.weight"], self.ed_dz[i - 1], 1,
-                             gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1])
-        ops.conv1d_dgrad(self.ed_dz[0], P["encoder.conv.0.net.0.weight"], dnotes, 1)
+            self._ed_conv_dgrad(i, self.ed_dz[i - 1])
+        self._ed_conv_dgrad(0, dnotes)
 
     # -------------------------------------------------------------------------------------
     # D-step  (src/gan/train_gan.py:183-205)
@@ -1100,10 +1137,21 @@ class GanEngine:
 
     def _adam(self, fp, lr):
         """The optimiser step; after draw_randoms() the Adam state is already advanced (fp.ticked)."""
-        ops.adam_flat(fp.data, fp.grad, fp.m, fp.v, fp.state, lr, *self.betas, grad_scale=1.0 / self.world_size,
-                      ticked_rng_step=self.rng_step if fp.ticked is True else None, ticked=bool(fp.ticked),
-                      wq=self._wq_tab["D" if fp is self.D else "GE"])
+        lo, wq = 0, self._wq_tab["D" if fp is self.D else "GE"]
+        if fp is self.GE and self._ge_head_done:          # [0, head) went out with g_backward_b's side branch
+            lo, wq, self._ge_head_done = self._ge_head, self._wq_tab["GE_rest"], False
+        ops.adam_flat(fp.data[lo:], fp.grad[lo:], fp.m[lo:], fp.v[lo:], fp.state, lr, *self.betas, grad_scale=1.0 / self.world_size,
+                      ticked_rng_step=self.rng_step if fp.ticked is True else None, ticked=bool(fp.ticked), wq=wq)
         fp.ticked = False
+
+    def _adam_ge_head(self):
+        """decoder.pre.2's share of the generator update, on its own: an elementwise update, so the split changes no bit.
+        Only with the state advanced by the step's draw (fp.ticked): this launch must not advance it."""
+        h = self._ge_head
+        fp = self.GE
+        ops.adam_flat(fp.data[:h], fp.grad[:h], fp.m[:h], fp.v[:h], fp.state, self.lr_g, *self.betas,
+                      grad_scale=1.0 / self.world_size, ticked=True)
+        self._ge_head_done = True
 
     def d_update(self):
         if self.coll is not None:           # C1 (gan/dp.py): the critic's gradient; a pending generator step's a_p0 rides along
@@ -1191,8 +1239,7 @@ class GanEngine:
                                      zout=self.ed_z[i], act=ACT_GELU)
                 else:
                     with ops.conv_lds_pad(lds_pad):
-                        ops.conv_gather(x, self.ed_wt[i], self.ed_a[i], co, k, 1, k, co * k, scale=self.ed_scale[i],
-                                        shift=self.ed_shift[i], zout=self.ed_z[i], act=ACT_GELU)
+                        self._ed_conv_fwd(i, x)
                 yield
                 x = self.ed_a[i]
             if bf16:
@@ -1257,11 +1304,10 @@ class GanEngine:
         yield
         for i in range(last, 0, -1):
             with ops.conv_lds_pad(lds_pad):
-                ops.conv1d_dgrad(self.ed_dz[i], P[f"encoder.conv.{i}.net.0.weight"], self.ed_dz[i - 1], 1,
-                                 gref=self.ed_z[i - 1], gact=ACT_GELU, gscale=self.ed_scale[i - 1])
+                self._ed_conv_dgrad(i, self.ed_dz[i - 1])
             yield
         with ops.conv_lds_pad(lds_pad):
-            ops.conv1d_dgrad(self.ed_dz[0], P["encoder.conv.0.net.0.weight"], dnotes, 1)
+            self._ed_conv_dgrad(0, dnotes)
         yield
 
     def g_critic_chain(self):
@@ -1320,12 +1366,14 @@ class GanEngine:
         # the three deconvolutions (their inputs and output gradients were kept by g_backward_a2) and the six small
         # Linear layers, 12 launches at the launch floor before.
         dn = self.dn_dense if self.dn_dense is not None else self.dnotes
-        jobs = list(extra_jobs)
+        jobs = []
+        # `big`: everything whose operands g_critic_back has left behind, 95 % of this pass's gradient FLOPs, as launches of
+        # their own (the same job list in every flow: a launch's slice plan -- hence the bits -- depends on its job list)
+        big = list(extra_jobs)
         if self.coll is not None and self.p2_world:         # C2: pre.2's factors of every rank -> its GLOBAL weight gradient
             self.coll.gather_p2(self, not self._a_p0_gathered)
-            jobs.append(ops.linear_wgrad(self.a_p0_all, self.d_p2_all, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
-                                         defer=True))
-        big = []                # everything whose operands g_critic_back has left behind: 95 % of this pass's gradient FLOPs
+            big.append(ops.linear_wgrad(self.a_p0_all, self.d_p2_all, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
+                                        defer=True))
         if not self.p2_world:
             big.append(ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
                                         defer=True))
@@ -1347,6 +1395,12 @@ class GanEngine:
             # the same bits (test_production_graphs_full_size_equal_eager_and_each_other)
             ops.wgrad_multi(big, tag="_side")
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
+        if tail_fork and self._ge_head and self.GE.ticked and os.environ.get("MELO_ADAM_SPLIT", "1") == "1":
+            # decoder.pre.2's share of the update (89 % of its bytes) leaves the critical path: behind the side branch's
+            # gradients AND behind the launch above, the last reader of pre.2's weights in this step
+            self.ed_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.ed_side):
+                self._adam_ge_head()
         jobs.append(ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"), defer=True))
         jobs.append(ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"),
                                      db=GG("noise_to_latent.net.2.bias"), defer=True))

@@ -153,6 +153,42 @@ def conv_gather(x: Tensor, w: Tensor, y: Tensor, N: int, K: int, stride: int, w_
     return y
 
 
+def wino3_supported(B: int, T: int, Cin: int, N: int) -> bool:
+    return bool(L.load().mg_conv1d_wino3_supported(B, T, Cin, N))
+
+
+def wino3_weights(w: Tensor, N: int, Cin: int, w_sn: int, w_sc: int, flip: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """The F(2,3) filter transform of a three-tap weight, (Cin/4, 4, N, 4) (mg_wino3_weights); `out`: an existing image to
+    refresh (a captured graph keeps reading the same buffer)."""
+    _chk(w, "w")
+    if w.numel() < (N - 1) * w_sn + (Cin - 1) * w_sc + 3:
+        raise ValueError("wino3_weights: w smaller than its strides imply")
+    wt = out if out is not None else torch.empty(Cin // 4, 4, N, 4, device=w.device, dtype=torch.float32)
+    _chk(wt, "wt", (Cin // 4, 4, N, 4))
+    L.check(L.load().mg_wino3_weights(_p(w), _p(wt), N, Cin, w_sn, w_sc, 1 if flip else 0, _stream()), "mg_wino3_weights")
+    return wt
+
+
+def conv_wino3(x: Tensor, wt: Tensor, y: Tensor, **epi) -> Tensor:
+    """Stride-1 three-tap convolution (padding 1) through minimal filtering (mg_conv1d_wino3).  x: (B, T, Cin);
+    wt: wino3_weights(...) (Cin/4, 4, N, 4); y: (B, T, N)."""
+    _chk(x, "x")
+    _chk(wt, "wt")
+    _chk(y, "y")
+    B, T, Cin = x.shape
+    N = wt.shape[2]
+    if tuple(wt.shape) != (Cin // 4, 4, N, 4) or tuple(y.shape) != (B, T, N):
+        raise ValueError(f"conv_wino3: wt {tuple(wt.shape)} / y {tuple(y.shape)} do not fit x {tuple(x.shape)}")
+    e = epilogue((B, T, N), N, **epi)
+    lib = L.load()
+    def launch():
+        return lib.mg_conv1d_wino3(_p(x), _p(wt), _p(y), B, T, Cin, N, C.byref(e), _stream())
+    with _observe(lambda: "wino3_kernel", 2.0 * B * T * N * Cin * 3, launch):      # the direct form's FLOPs (algorithmic)
+        rc = launch()
+    L.check(rc, "mg_conv1d_wino3")
+    return y
+
+
 def conv_scatter2(x: Tensor, w: Tensor, y: Tensor, N: int, w_sn: int, w_sc: int, odd: bool = False, **epi) -> Tensor:
     """Stride-2 K=5 transposed window-GEMM (see mg_conv1d_scatter2).  x: (B, Tin, Cin); y: (B, Ty>=Tout, N),
     Tout = 2*Tin, or 2*Tin-1 with odd=True (dgrad of a stride-2 conv over an odd-length input)."""
