@@ -14,10 +14,11 @@ second window of max(K, 64) steps between its own pair of HIP events on the engi
 median / p10 / p90 per step (median of >= 50 hipEvent-timed iterations).
 
 The same JSON line carries
-  roofline     : the dominant kernel SYMBOL (stride-1 K=3 64x64-tile window-GEMM: ED conv1-3 forward and their
-                 data-gradients, 6 launches = 20.9 of the step's 56.9 GFLOP).  The launches are recorded during
-                 one step and replayed (same tensors, one hipGraph, HIP events on the launch stream): algorithmic
-                 FLOPs / that time, against the dense fp32-MFMA peak (157.3 TFLOP/s);
+  roofline     : the dominant kernel SYMBOL (wino3_kernel: the emotion discriminator's three-tap layers by minimal
+                 filtering F(2,3), 5 launches = 20.1 of the step's 56.9 algorithmic GFLOP).  The launches are recorded
+                 during one step and replayed (same tensors, HIP events on the launch stream): ALGORITHMIC (direct-form)
+                 FLOPs / that time, against the dense fp32-MFMA peak (157.3 TFLOP/s) -- the kernel EXECUTES 2/3 of those
+                 FLOPs on the matrix pipe, `mfma_executed_frac` is the pipe's own utilisation;
   cpu_baseline : the oracle (PyTorch-CPU fp32 restatement of the reference step) timed on this
                  host on a bounded number of the same steps (rank 0, N=1 only): once with every physical
                  core this process may use, once with 1 thread; CPU model and counts stated.
@@ -35,10 +36,14 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 B_PER_GPU, T, C = 64, 256, 128
-# the dominant kernel: stride-1 K=3 64x64-tile window GEMM, both weight-layout instantiations (forward / data-gradient)
-DOMINANT = ("conv_wgemm_kernel<1,3,false,true,1,1>", "conv_wgemm_kernel<1,3,false,false,1,1>")
-DOMINANT_NAME = "conv_wgemm_kernel<1,3,false,{true|false},1,1>"
-# second MFMA-bound family, reported beside it: the stride-2 five-tap window GEMMs of the critic and the generator
+# the dominant kernel: the emotion discriminator's three-tap layers by minimal filtering F(2,3) (csrc/conv_wino.hip: conv1-3
+# forward, conv2-3 data-gradient = 5 launches, 20.1 of the step's algorithmic GFLOP); MELO_ED_WINO=0 puts the direct
+# stride-1 K=3 window GEMM back (both weight-layout instantiations)
+DOMINANT = ("wino3_kernel",)
+DOMINANT_NAME = "wino3_kernel"
+DOMINANT_DIRECT = ("conv_wgemm_kernel<1,3,false,true,1,1>", "conv_wgemm_kernel<1,3,false,false,1,1>")
+DOMINANT_DIRECT_NAME = "conv_wgemm_kernel<1,3,false,{true|false},1,1>"
+WINO_EXECUTED = 2.0 / 3.0        # matrix-pipe FLOPs executed per algorithmic (direct-form) FLOP: 4 channel GEMMs per output pair, not 6
 CONV16 = tuple("conv16_kernel<%s,%d,%s>" % (a, b, c) for a in ("false", "true") for b in (1, 2) for c in ("false", "true"))
 CONV16_NAME = "conv16_kernel<{false|true},{1|2},{false|true}>"
 PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
@@ -485,7 +490,7 @@ def main():
         # ---- roofline leg: the dominant kernel's launches of one step, recorded and replayed under HIP events ----
         roof = roof2 = None
         if rank == 0 and args.profile_steps > 0:
-            hook = RecordHook(DOMINANT + CONV16)
+            hook = RecordHook(DOMINANT + DOMINANT_DIRECT + CONV16)
             ops.set_launch_hook(hook)
             # the production launch sequence of one step, eagerly (the hook sees every launch) -- through a LOCAL wrapper and
             # with the engine's in-graph collectives switched off: only rank 0 runs this leg, so it must not issue
@@ -510,14 +515,24 @@ def main():
                             how="one dispatch at a time (recorded launches replayed, HIP event pair each)",
                             launches=launches, launches_per_step=len(recs), avg_us=round(1e3 * ms / launches, 2),
                             avg_gflop_per_launch=round(flops / launches / 1e9, 3))
-            roof = leg(DOMINANT, DOMINANT_NAME)
+            dom, dom_name = DOMINANT, DOMINANT_NAME
+            roof = leg(dom, dom_name)
+            if roof is None:                      # MELO_ED_WINO=0: the direct window GEMM is the dominant symbol again
+                dom, dom_name = DOMINANT_DIRECT, DOMINANT_DIRECT_NAME
+                roof = leg(dom, dom_name)
+            elif any(r[0] in DOMINANT_DIRECT for r in hook.records):
+                roof["note"] = ("conv1's data-gradient (64 output columns) stays on the direct window GEMM "
+                                "(conv_wgemm_kernel<1,3,...>): not in this symbol")
+            if roof is not None and dom is DOMINANT:
+                roof["mfma_executed_frac"] = round(roof["frac"] * WINO_EXECUTED, 4)
+                roof["flops"] = "algorithmic = the direct convolution's 2*B*T*N*Cin*3 per launch; executed on the matrix pipe: 2/3 of it"
             roof2 = leg(CONV16, CONV16_NAME)
             # the same kernels INSIDE the step (two streams, as replayed): frac_in_step is the figure to hold against the
             # rocprofv3 per-kernel average of profiles/; `frac` / `achieved` stay the one-dispatch-at-a-time measurement
             keep = (eng.coll, eng.p2_world, eng.world_size)
             eng.coll, eng.p2_world = None, 0
             try:
-                for r_, syms in ((roof, DOMINANT), (roof2, CONV16)):
+                for r_, syms in ((roof, dom), (roof2, CONV16)):
                     if r_ is None:
                         continue
                     ms_i, fl_i, n_i = time_in_step(ops, eng, syms, max(4, args.profile_steps // 2))
@@ -532,13 +547,19 @@ def main():
                 roof["traffic_provenance"] = prov
                 # algorithmic bytes per launch, averaged over the six launches of a step (ED conv1-3: forward reads x and w,
                 # writes the activation AND the pre-activation; data-gradient reads dy, the saved pre-activation and w, writes dx)
-                algo = 0.0
+                algo, n_l = 0.0, 0
                 for ci, co in ((64, 128), (128, 256), (256, 256)):
                     xb, yb, wb = 4.0 * B_PER_GPU * T * ci, 4.0 * B_PER_GPU * T * co, 4.0 * ci * co * 3
-                    algo += (xb + 2 * yb + wb) + (yb + 2 * xb + wb)
-                roof["traffic_algorithmic"] = round(algo / 6, 0)
+                    algo += xb + 2 * yb + wb
+                    n_l += 1
+                    if dom is DOMINANT_DIRECT or ci >= 128:      # conv1's data-gradient is not a wino3 launch
+                        algo += yb + 2 * xb + wb
+                        n_l += 1
+                roof["traffic_algorithmic"] = round(algo / n_l, 0)
                 if tb:
-                    roof["traffic_over_algorithmic"] = round(tb / (algo / 6), 3)
+                    roof["traffic_over_algorithmic"] = round(tb / (algo / n_l), 3)
+                if "in_step" in roof and dom is DOMINANT:
+                    roof["in_step"]["mfma_executed_frac"] = round(roof["in_step"]["frac"] * WINO_EXECUTED, 4)
         if rank == 0 and args.launch_flops:
             tally = {}
 

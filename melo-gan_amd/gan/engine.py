@@ -1370,37 +1370,41 @@ class GanEngine:
         # `big`: everything whose operands g_critic_back has left behind, 95 % of this pass's gradient FLOPs, as launches of
         # their own (the same job list in every flow: a launch's slice plan -- hence the bits -- depends on its job list)
         big = list(extra_jobs)
+        p2_job = None
         if self.coll is not None and self.p2_world:         # C2: pre.2's factors of every rank -> its GLOBAL weight gradient
             self.coll.gather_p2(self, not self._a_p0_gathered)
-            big.append(ops.linear_wgrad(self.a_p0_all, self.d_p2_all, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
-                                        defer=True))
+            p2_job = ops.linear_wgrad(self.a_p0_all, self.d_p2_all, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"), defer=True)
         if not self.p2_world:
-            big.append(ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"),
-                                        defer=True))
+            p2_job = ops.linear_wgrad(self.a_p0, self.d_p2, GG("decoder.pre.2.weight"), db=GG("decoder.pre.2.bias"), defer=True)
         big.append(ops.convT1d_wgrad(self.a_d3, dn, GG("decoder.deconv.6.weight"), db=GG("decoder.deconv.6.bias"), defer=True))
         big.append(ops.convT1d_wgrad(self.a_d0, self.d_zd3, GG("decoder.deconv.3.weight"), db=GG("decoder.deconv.3.bias"),
                                      defer=True))
         big.append(ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"),
                                      defer=True))
         tail_fork = self._tail_fork and self.ed_side is not None and self.coll is None
-        if tail_fork:
-            # the forked step graph's second fork: these gradients on the side stream BESIDE the small dependent launches
-            # below (pre.2's data-gradient, the back chain, the LayerNorm parameters), which leave the chip nearly empty
-            cur = torch.cuda.current_stream()
-            self.ed_side.wait_stream(cur)
-            with torch.cuda.stream(self.ed_side):
-                ops.wgrad_multi(big, tag="_side")
-        else:
-            # the same launches on this stream: a launch's slice plan depends on its job list, and every flow must produce
-            # the same bits (test_production_graphs_full_size_equal_eager_and_each_other)
-            ops.wgrad_multi(big, tag="_side")
+        split = tail_fork and self._ge_head and self.GE.ticked and os.environ.get("MELO_ADAM_SPLIT", "1") == "1"
+        cur = torch.cuda.current_stream()
+
+        def side(fn):
+            """The forked step graph's second fork: pre.2's and the deconvolutions' gradients (and pre.2's share of the update)
+            on the side stream BESIDE the small dependent launches below (pre.2's data-gradient, the back chain, the LayerNorm
+            parameters), which leave the chip nearly empty.  Other flows: the same launches on this stream -- a launch's
+            slice plan depends on its job list, and every flow must produce the same bits."""
+            if tail_fork:
+                self.ed_side.wait_stream(cur)
+                with torch.cuda.stream(self.ed_side):
+                    fn()
+            else:
+                fn()
+        if p2_job is not None:
+            side(lambda: ops.wgrad_multi([p2_job], tag="_side"))
+        side(lambda: ops.wgrad_multi(big, tag="_side2"))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
-        if tail_fork and self._ge_head and self.GE.ticked and os.environ.get("MELO_ADAM_SPLIT", "1") == "1":
-            # decoder.pre.2's share of the update (89 % of its bytes) leaves the critical path: behind the side branch's
-            # gradients AND behind the launch above, the last reader of pre.2's weights in this step
-            self.ed_side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.ed_side):
-                self._adam_ge_head()
+        if split:
+            # decoder.pre.2's share of the update (89 % of its bytes) leaves the critical path: behind its gradient AND behind
+            # the launch above, the last reader of pre.2's weights in this step (measured: the update behind the
+            # deconvolutions' gradients 0.845, in front of them 0.849 ms per step, same box, four alternations)
+            side(self._adam_ge_head)
         jobs.append(ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"), defer=True))
         jobs.append(ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"),
                                      db=GG("noise_to_latent.net.2.bias"), defer=True))

@@ -17,10 +17,12 @@ echo "[4/7] FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/
 echo "[5/7] WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $R/bench.py --no-graph --steps 6 --warmup 2 --no-cpu-baseline --profile-steps 0 > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch/f_counter_collection.csv $OUT/pmc_write/w_counter_collection.csv > $OUT/traffic_dominant_kernel.json; rm -rf $OUT/pmc_fetch $OUT/pmc_write
 echo "[6/7] layer benches"; python3 $R/tools/layer_bench.py > $OUT/layer_bench.txt 2>/dev/null; python3 $R/tools/conv16_bench.py > $OUT/conv16_bench.txt 2>/dev/null
+python3 $R/tools/wino_bench.py > $OUT/wino_bench.txt 2>/dev/null
 echo "[7/7] other workloads"; python3 $R/tools/ref_shape_bench.py > $OUT/other_workloads.txt 2>/dev/null
 for w in ae gen1 ed; do python3 $R/bench.py --workload $w --no-cpu-baseline >> $OUT/other_workloads.txt 2>/dev/null; done
 ls -la $OUT
 echo "[8/8] chains + timeline"; (cd $R/tools && python3 chain_bench.py > $OUT/chain_bench.txt 2>/dev/null; python3 ed_pad_bench.py > $OUT/ed_pad_bench.txt 2>/dev/null)
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl -o s -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --profile-steps 0 > /dev/null 2>&1
 python3 $R/tools/timeline.py $OUT/tl/s_kernel_trace.csv 30 > $OUT/step_timeline.txt; rm -rf $OUT/tl
+python3 $R/tools/step_stamps.py 200 > $OUT/step_stamps.txt 2>/dev/null
 ls -la $OUT

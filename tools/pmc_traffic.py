@@ -1,4 +1,4 @@
-"""HBM bytes per launch of the dominant window-GEMM kernel from two rocprofv3 PMC passes (one counter per pass, as
+"""HBM bytes per launch of the dominant kernel (wino3_kernel; argv[3] = another kernel-name regex) from two rocprofv3 PMC passes (one counter per pass, as
 MI355X_MICROARCH.md's HBM section prescribes; never combined with trace domains):
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/pmc_fetch -o f -- python3 bench.py --no-graph --steps 6 --warmup 2 --no-cpu-baseline --profile-steps 0
@@ -11,7 +11,8 @@ import json
 import re
 import sys
 
-PAT = re.compile(r"conv_wgemm_kernel<1, 3, false, (true|false), 1, 1>")
+PAT = re.compile(sys.argv[3] if len(sys.argv) > 3 else r"wino3_kernel")
+NAME = sys.argv[3] if len(sys.argv) > 3 else "wino3_kernel"
 
 
 def avg(path, counter):
@@ -28,7 +29,7 @@ if __name__ == "__main__":
     fetch, nf = avg(sys.argv[1], "FETCH_SIZE")
     write, nw = avg(sys.argv[2], "WRITE_SIZE")
     print(json.dumps({
-        "kernel": "conv_wgemm_kernel<1,3,false,{true|false},1,1>",
+        "kernel": NAME,
         "launches": nf,
         "fetch_size_kb_avg": fetch,
         "write_size_kb_avg": write,
