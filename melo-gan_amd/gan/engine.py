@@ -658,6 +658,8 @@ class GanEngine:
         """The fused step's draw: noise and dropout masks of BOTH halves plus alpha in one launch, which advances both
         optimisers' Adam states; the critic update advances the Philox counter."""
         self._stamp(0)
+        # (Tried: the staging launch on the side stream beside the draw -- a fork and a join for two 5-10-us launches: 75.4 k
+        # samples/s against 76.2 k without.)
         self._stage_bound()
         ops.rng_fill(self.noise_2, self.alpha, self.dmask_2[0], self.dmask_2[1], P_DROP, self.rng_seed, self.rng_step,
                      tick_state=self.D.state, betas=self.betas, tick_state2=self.GE.state)
@@ -969,6 +971,9 @@ class GanEngine:
                                    gact=ACT_LRELU).pooled
         # the three convolutions' weight gradients go out as ONE launch (+ one slab reduction) once their tangents
         # exist (ops.wgrad_multi): three launches of ~256 workgroups each plus three reductions before
+        # (Tried: this launch on a THIRD stream beside the small dependent launches below.  With three streams in the forked
+        # graph the emotion branch's first node ran 236 us after the fork instead of 10 -- mg_stamp -- and the step went from
+        # 0.835 to 0.88 ms: a forked hipGraph keeps two branches concurrent, not three.)
         ops.wgrad_multi([
             ops.conv1d_wgrad(self.X0[B:3 * B], self.dZ1[B:], G["conv.0.weight"], 2, self.TAN0, self.dZ1[:B],
                              db=G["conv.0.bias"], defer=True),
