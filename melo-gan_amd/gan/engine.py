@@ -326,6 +326,7 @@ class GanEngine:
         # side stream of the fused step's emotion branch (dg_step_rng); MELO_ED_SIDE=0: everything on one stream
         self.ed_side = torch.cuda.Stream(device=d) if os.environ.get("MELO_ED_SIDE", "1") == "1" else None
         self._tail_fork = False         # set by the forked step around g_backward_b
+        self._d_wgrad_side, self._d_wgrad_ev = False, None
         self.ed_side_lds_pad = int(os.environ.get("MELO_ED_LDS_PAD", "42000"))      # g_ed_branch_side
         # its data-gradient convolutions: the same cap.  (In the forked-graph flow they mostly run after the main branch has
         # reached the join, yet lifting the cap for them measured SLOWER: 0.867 -> 0.882 ms per step; alone on the chip a
@@ -974,13 +975,25 @@ class GanEngine:
         # (Tried: this launch on a THIRD stream beside the small dependent launches below.  With three streams in the forked
         # graph the emotion branch's first node ran 236 us after the fork instead of 10 -- mg_stamp -- and the step went from
         # 0.835 to 0.88 ms: a forked hipGraph keeps two branches concurrent, not three.)
-        ops.wgrad_multi([
+        wjobs = [
             ops.conv1d_wgrad(self.X0[B:3 * B], self.dZ1[B:], G["conv.0.weight"], 2, self.TAN0, self.dZ1[:B],
                              db=G["conv.0.bias"], defer=True),
             ops.conv1d_wgrad(self.A1[B:], self.dZ2[B:], G["conv.2.weight"], 2, self.TAN1, self.dZ2[:B],
                              db=G["conv.2.bias"], defer=True),
             ops.conv1d_wgrad(self.A2[B:], self.dZ3[B:], G["conv.4.weight"], 2, self.TAN2, self.dZ3[:B],
-                             db=G["conv.4.bias"], defer=True)])
+                             db=G["conv.4.bias"], defer=True)]
+        if self._d_wgrad_side:
+            # forked step graph: this launch (+ its slab reduction), 70 us of the critic step, goes INTO the emotion branch's
+            # stream -- that branch has the slack since its three-tap layers run on minimal filtering -- beside the three
+            # small dependent launches below; d_update waits for it
+            cur = torch.cuda.current_stream()
+            self.ed_side.wait_stream(cur)
+            with torch.cuda.stream(self.ed_side):
+                ops.wgrad_multi(wjobs)
+                self._d_wgrad_ev = torch.cuda.Event()
+                self._d_wgrad_ev.record(self.ed_side)
+        else:
+            ops.wgrad_multi(wjobs)
         if not tz3_pooled:
             ops.meanT_fwd(self.TZ3, self.ghb)
         ops.linear_fwd(self.ghb, P["fc.1.weight"], self.gfb, gref=self.Fh[:B], gact=ACT_LRELU)
@@ -1057,16 +1070,16 @@ class GanEngine:
         self.g_update()
 
     def _fork_branches(self):
-        """The two parallel branches between fork and join.  What the runtime does with a forked hipGraph (kernel traces,
-        round 3): it assigns the branches to queues of its own, and the emotion branch's first kernel starts 150-200 us after
-        the fork node has finished WHATEVER the capture looks like -- main branch first (0.866 ms per step), the branches'
-        launches interleaved (MELO_FORK_ORDER=interleave: 0.866), the emotion branch on the capturing stream and everything
-        else on the side stream (0.868), a side-stream node at the graph's root (0.883), two alternating executables
-        (0.897); only the emotion branch captured first is different, and worse (0.881).  hipGraphLaunch of the forked graph
-        also costs the host 0.74 ms per step (0.10 for the split flow's four linear graphs) and the host does not get
-        ahead of the GPU.  The main branch then waits ~180 us at the join; the four linear graphs of the split flow start
-        both branches at once but pay three graph boundaries (0.886).  Default: main_first."""
-        order = os.environ.get("MELO_FORK_ORDER", "main_first")
+        """The two parallel branches between fork and join: the critic step + the critic pass on the generated batch (this
+        stream) beside the frozen emotion discriminator's branch (side stream).  Measured with mg_stamp inside the replayed
+        graph (tools/step_stamps.py; the profiler's timeline of a forked graph is NOT the truth -- DESIGN section 6): the
+        branch starts ~10 us after the fork; a forked hipGraph keeps TWO branches concurrent (a third stream delayed the
+        branch's first node by 236 us); capture order does not matter.  Since the branch's three-tap layers run on minimal
+        filtering it has ~70 us of slack against this stream, so the critic's convolution weight gradients (one launch + slab
+        reduction, ~70 us) are enqueued INTO the branch's stream behind its classifier-tail chain (order "dwgrad_side", the
+        default: 77.2 k samples/s against 76.3 k for "main_first", three alternations on one box; behind the pooling backward:
+        the same; one launch later: no gain).  Other orders kept for experiments: main_first, ed_first, interleave."""
+        order = os.environ.get("MELO_FORK_ORDER", "dwgrad_side")
         if order == "ed_first" or (order == "interleave" and not self._chain_ed):
             with torch.cuda.stream(self.ed_side):
                 self.g_ed_branch_side()
@@ -1074,6 +1087,26 @@ class GanEngine:
         if order == "interleave":
             self._require_fold()
             self._il = self._ed_steps(self.ed_side_lds_pad, self.ed_side_lds_pad_bwd)
+        if order == "dwgrad_side" and self._chain_ed and self.ed_mode == "notes" and self.ed_dtype == "fp32":
+            self._require_fold()
+            il = self._ed_steps(self.ed_side_lds_pad, self.ed_side_lds_pad_bwd)
+            n_first = len(self.ed_chans) + int(os.environ.get("MELO_DWGRAD_AFTER", "1"))   # forward convs + the tail chain
+            with torch.cuda.stream(self.ed_side):
+                self._stamp(2)
+                for _ in range(n_first):
+                    next(il)
+            self._d_wgrad_side = True
+            try:
+                self.d_backward(forward=False)
+            finally:
+                self._d_wgrad_side = False
+            with torch.cuda.stream(self.ed_side):
+                for _ in il:
+                    pass
+                self._stamp(3)
+            self.d_update()
+            self.g_critic_front()
+            return
         self.d_backward(forward=False)
         self.d_update()
         self.g_critic_front()
@@ -1159,6 +1192,9 @@ class GanEngine:
         self._ge_head_done = True
 
     def d_update(self):
+        if self._d_wgrad_ev is not None:
+            torch.cuda.current_stream().wait_event(self._d_wgrad_ev)
+            self._d_wgrad_ev = None
         if self.coll is not None:           # C1 (gan/dp.py): the critic's gradient; a pending generator step's a_p0 rides along
             self.coll.reduce_d(self, self._p2_pending and not self._a_p0_gathered)
             self._a_p0_gathered = self._p2_pending
