@@ -418,6 +418,27 @@ int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, 
  *      apart (0: dense), so a job can also fill a column block of a wider matrix.  idx is a
  *      device array of n_rows int64 indices, clamped into [0, src_rows) on the device (an out-of-range index never
  *      reads outside the source). */
+/* ---- spectral normalisation of a weight (torch.nn.utils.spectral_norm, dim 0, n_power_iterations 1, eps 1e-12) ----
+ * The reference wraps the emotion discriminator's Conv1d / Linear layers in it when `use_spectral_norm` is set
+ * (src/emotion_discriminator/ed_model.py:29-32,79-82; FeatureEncoder(use_sn): src/gan/feature_encoder.py:24-31).
+ * weight_mat = w_orig as (rows = out, cols = everything else).  One launch serves several layers.
+ *   mg_spectral_norm_fwd: power_iterations = 1 (training forward): v = normalize(W^T u), u = normalize(W v), in place;
+ *                         then (also with 0 = eval) sigma = u . (W v) and w_eff = w_orig / sigma.
+ *   mg_spectral_norm_bwd: dw (the gradient w.r.t. w_eff, in place) <- (dw - <dw, w_eff> u v^T) / sigma = the gradient w.r.t.
+ *                         w_orig (u, v constants, as autograd sees them). */
+#define MG_MAX_SN_JOBS 8
+typedef struct mg_sn_job {
+    const float* w_orig;
+    float* w_eff;
+    float* u;       /* (rows) */
+    float* v;       /* (cols) */
+    float* sigma;   /* (1) */
+    float* dw;      /* bwd only */
+    int rows, cols;
+} mg_sn_job;
+int mg_spectral_norm_fwd(const mg_sn_job* jobs, int n_jobs, int power_iterations, float eps, mg_stream_t stream);
+int mg_spectral_norm_bwd(const mg_sn_job* jobs, int n_jobs, mg_stream_t stream);
+
 #define MG_MAX_STAGE_JOBS 8
 typedef struct mg_stage_job {
     const void* src;

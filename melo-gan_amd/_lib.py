@@ -45,6 +45,13 @@ class StageJob(C.Structure):
 MAX_STAGE_JOBS = 8
 
 
+class SnJob(C.Structure):
+    _fields_ = [("w_orig", vp), ("w_eff", vp), ("u", vp), ("v", vp), ("sigma", vp), ("dw", vp), ("rows", i32), ("cols", i32)]
+
+
+MAX_SN_JOBS = 8
+
+
 class WgradJob(C.Structure):
     _fields_ = [("s0", vp), ("l0", vp), ("nb0", i32), ("s1", vp), ("l1", vp), ("nb1", i32),
                 ("out", vp), ("bias_out", vp), ("bias_from", i32), ("Ts", i32), ("Tl", i32), ("A", i32), ("Bc", i32)]
@@ -111,6 +118,8 @@ SIGNATURES = {
     "mg_row_chain": (i32, [vp, i32, i32, vp]),
     "mg_mean_scaled": (i32, [vp, vp, i32, f32, vp]),
     "mg_stamp": (i32, [vp, vp]),
+    "mg_spectral_norm_fwd": (i32, [vp, i32, i32, f32, vp]),
+    "mg_spectral_norm_bwd": (i32, [vp, i32, vp]),
     "mg_conv1d_wino3_supported": (i32, [i32, i32, i32, i32]),
     "mg_wino3_weights": (i32, [vp, vp, i32, i32, i64, i64, i32, vp]),
     "mg_conv1d_wino3": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),

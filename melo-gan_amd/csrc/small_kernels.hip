@@ -1043,6 +1043,84 @@ __global__ __launch_bounds__(256) void norm_clip_final_kernel(const float* part,
     }
 }
 
+// ---------------- spectral normalisation (torch.nn.utils.spectral_norm, dim 0, one power iteration) ----------------
+// One 1024-thread workgroup per layer.  weight_mat = w_orig viewed (rows = out, cols = in * k).  power_iter (training forward):
+//   v = normalize(W^T u), u = normalize(W v)  (x / max(|x|_2, eps), in place in the module's buffers),
+// then always  sigma = u . (W v),  w_eff = w_orig / sigma  (reference: src/emotion_discriminator/ed_model.py:29-32,79-82 wrap
+// Conv1d / Linear in torch.nn.utils.spectral_norm; the algorithm restated is torch's SpectralNorm.compute_weight).
+struct SnJobs { mg_sn_job j[MG_MAX_SN_JOBS]; int n; };
+
+__global__ __launch_bounds__(1024) void spectral_norm_fwd_kernel(const SnJobs J, int power_iter, float eps) {
+    __shared__ float sh[16];
+    const mg_sn_job jb = J.j[blockIdx.x];
+    const int R = jb.rows, Cc = jb.cols;
+    const float* __restrict__ W = jb.w_orig;
+    float* u = jb.u;
+    float* v = jb.v;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (power_iter) {
+        // v = W^T u: a thread per column (coalesced along the columns), rows in sequence
+        for (int j = tid; j < Cc; j += 1024) {
+            float acc = 0.f;
+            for (int i = 0; i < R; ++i) acc += W[(long)i * Cc + j] * u[i];
+            v[j] = acc;
+        }
+        __threadfence_block();
+        __syncthreads();
+        float q = 0.f;
+        for (int j = tid; j < Cc; j += 1024) q += v[j] * v[j];
+        q = block_sum(q, sh);
+        const float sv = 1.f / fmaxf(sqrtf(q), eps);
+        for (int j = tid; j < Cc; j += 1024) v[j] *= sv;
+        __threadfence_block();
+        __syncthreads();
+        // u = W v: a wave per row
+        for (int i = wave; i < R; i += 16) {
+            float acc = 0.f;
+            for (int j = lane; j < Cc; j += 64) acc += W[(long)i * Cc + j] * v[j];
+            acc = wave_sum(acc);
+            if (lane == 0) u[i] = acc;
+        }
+        __threadfence_block();
+        __syncthreads();
+        float r = 0.f;
+        for (int i = tid; i < R; i += 1024) r += u[i] * u[i];
+        r = block_sum(r, sh);
+        const float su = 1.f / fmaxf(sqrtf(r), eps);
+        for (int i = tid; i < R; i += 1024) u[i] *= su;
+        __threadfence_block();
+        __syncthreads();
+    }
+    float part = 0.f;
+    for (int i = wave; i < R; i += 16) {
+        float acc = 0.f;
+        for (int j = lane; j < Cc; j += 64) acc += W[(long)i * Cc + j] * v[j];
+        acc = wave_sum(acc);
+        if (lane == 0) part += u[i] * acc;
+    }
+    const float sigma = block_sum(part, sh);
+    if (tid == 0) jb.sigma[0] = sigma;
+    const long n = (long)R * Cc;
+    for (long e = tid; e < n; e += 1024) jb.w_eff[e] = W[e] / sigma;
+}
+
+// gradient through w_eff = w_orig / sigma, sigma = u . (w_orig v) with u, v constants:
+//   d w_orig = (d w_eff - <d w_eff, w_eff> u v^T) / sigma        (in place in dw)
+__global__ __launch_bounds__(1024) void spectral_norm_bwd_kernel(const SnJobs J) {
+    __shared__ float sh[16];
+    const mg_sn_job jb = J.j[blockIdx.x];
+    const int Cc = jb.cols;
+    const long n = (long)jb.rows * Cc;
+    float d = 0.f;
+    for (long e = threadIdx.x; e < n; e += 1024) d += jb.dw[e] * jb.w_eff[e];
+    d = block_sum(d, sh);
+    const float inv = 1.f / jb.sigma[0];
+    for (long e = threadIdx.x; e < n; e += 1024) {
+        const int i = (int)(e / Cc), j = (int)(e - (long)i * Cc);
+        jb.dw[e] = (jb.dw[e] - d * jb.u[i] * jb.v[j]) * inv;
+    }
+}
+
 // ---------------- VAE ----------------
 __global__ void reparam_kernel(const float* mu, const float* lv, const float* eps, float* z, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1574,6 +1652,35 @@ int mg_adam_flat_wq(float* p, const float* g, float* m, float* v, long n, float 
     hipLaunchKernelGGL(adam_apply_kernel, dim3(nblk(n)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, (const double*)state, grad_scale, gs_dev, (unsigned long long*)rng_step, t);
     MG_CHECK_LAUNCH("adam_flat_wq");
+    return MG_OK;
+}
+
+static int sn_jobs(const mg_sn_job* jobs, int n_jobs, bool bwd, SnJobs& J, const char* who) {
+    MG_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= MG_MAX_SN_JOBS, "%s: 1..%d jobs", who, MG_MAX_SN_JOBS);
+    J.n = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        const mg_sn_job& q = jobs[i];
+        MG_CHECK_ARG(q.w_eff && q.u && q.v && q.sigma && q.rows > 0 && q.cols > 0 && (bwd ? q.dw != nullptr : q.w_orig != nullptr),
+                     "%s: job %d: null tensor or empty shape", who, i);
+        J.j[i] = q;
+    }
+    return MG_OK;
+}
+
+int mg_spectral_norm_fwd(const mg_sn_job* jobs, int n_jobs, int power_iterations, float eps, mg_stream_t stream) {
+    SnJobs J{};
+    if (int rc = sn_jobs(jobs, n_jobs, false, J, "mg_spectral_norm_fwd")) return rc;
+    MG_CHECK_ARG(power_iterations == 0 || power_iterations == 1, "mg_spectral_norm_fwd: 0 (eval) or 1 power iteration");
+    hipLaunchKernelGGL(spectral_norm_fwd_kernel, dim3((unsigned)n_jobs), dim3(1024), 0, ST, J, power_iterations, eps);
+    MG_CHECK_LAUNCH("spectral_norm_fwd");
+    return MG_OK;
+}
+
+int mg_spectral_norm_bwd(const mg_sn_job* jobs, int n_jobs, mg_stream_t stream) {
+    SnJobs J{};
+    if (int rc = sn_jobs(jobs, n_jobs, true, J, "mg_spectral_norm_bwd")) return rc;
+    hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3((unsigned)n_jobs), dim3(1024), 0, ST, J);
+    MG_CHECK_LAUNCH("spectral_norm_bwd");
     return MG_OK;
 }
 

@@ -6,6 +6,11 @@ the GAN hot path lives in melo_gan_amd.gan.engine.GanEngine.
 Layout: activations (B, T, C) channels-last like everywhere else; parameters / gradients / Adam moments in one flat
 fp32 buffer each (one fused AdamW launch); BatchNorm running statistics in `buf`.  Backward is hand-derived:
   logits -> classifier (Linear, GELU, Dropout)* -> project Linear -> mean over T -> [GELU, BatchNorm(train), Conv1d]*.
+
+`use_spectral_norm: true` (ed_model.py:29-32,79-82: every encoder Conv1d and the classifier's hidden Linear layers wrapped in
+torch.nn.utils.spectral_norm): the flat parameter buffer holds weight_orig, the buffers hold weight_u / weight_v; one launch
+per forward runs the power iteration (training mode) and writes the effective weights w_orig / sigma the layers then use
+(mg_spectral_norm_fwd), one launch after the weight gradients turns d w_eff into d w_orig (mg_spectral_norm_bwd).
 """
 from __future__ import annotations
 
@@ -56,6 +61,20 @@ class EdEngine:
                 self.buf[k] = torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d)
         self.chans = chans
         self.mlp = tuple(cfg.get("mlp_hidden", (256, 128)))
+        # spectral normalisation: which layers, their u / v buffers (module state), effective weights and sigmas (derived)
+        self.sn_names = []
+        if cfg.get("use_spectral_norm", False):
+            self.sn_names = [f"encoder.conv.{i}.net.0" for i in range(len(chans))] + [f"classifier.net.{3 * j}" for j in range(len(self.mlp))]
+        if share is not None:
+            self.w_eff, self.sn_sigma = share.w_eff, share.sn_sigma
+        else:
+            self.w_eff, self.sn_sigma = {}, {}
+            for nm in self.sn_names:
+                shp = spec[nm + ".weight"]
+                self.buf[nm + ".weight_u"] = torch.zeros(shp[0], device=d)
+                self.buf[nm + ".weight_v"] = torch.zeros(math.prod(shp[1:]), device=d)
+                self.w_eff[nm] = torch.zeros(shp, device=d)
+                self.sn_sigma[nm] = torch.ones(1, device=d)
         hid = cfg.get("notes_hidden", 256)
         f = lambda *s: torch.empty(*s, device=d)      # noqa: E731
         self.x = f(B, T, C)
@@ -93,7 +112,11 @@ class EdEngine:
             bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
             self.P.p[k].copy_((torch.rand(s, generator=g) * 2 - 1) * bound)
         for k, v in self.buf.items():
-            v.fill_(1.0 if k.endswith("running_var") else 0.0)
+            if k.endswith("weight_u") or k.endswith("weight_v"):      # torch: normalize(randn) (spectral_norm.py, SpectralNorm.apply)
+                r = torch.randn(v.shape, generator=g)
+                v.copy_(r / r.norm().clamp_min(1e-12))
+            else:
+                v.fill_(1.0 if k.endswith("running_var") else 0.0)
 
     def set_lr(self, lr: float):
         """ReduceLROnPlateau: the learning rate is a launch argument of the AdamW kernel, baked into every captured
@@ -116,8 +139,16 @@ class EdEngine:
         return self._tails[rows]
 
     def load_state(self, params: Dict[str, Tensor], buffers: Optional[Dict[str, Tensor]] = None):
+        """params may be a torch state_dict of the reference module: a spectrally normalised layer's weight is `weight_orig`
+        there, its `weight_u` / `weight_v` are buffers (taken from `params` too when `buffers` lacks them)."""
+        params = dict(params)
+        for nm in self.sn_names:
+            if nm + ".weight_orig" in params:
+                params[nm + ".weight"] = params[nm + ".weight_orig"]
         self.P.load(params)
-        for k, v in (buffers or {}).items():
+        src = dict(params)
+        src.update(buffers or {})
+        for k, v in src.items():
             if k in self.buf:
                 self.buf[k].copy_(v.to(torch.float32))
 
@@ -135,6 +166,10 @@ class EdEngine:
         for k, v in P.items():
             if k not in sd:
                 sd[k] = v
+        for nm in self.sn_names:          # torch.nn.utils.spectral_norm's keys: weight_orig (parameter), weight_u, weight_v (buffers)
+            sd[nm + ".weight_orig"] = sd.pop(nm + ".weight")
+            sd[nm + ".weight_u"] = self.buf[nm + ".weight_u"].cpu().clone()
+            sd[nm + ".weight_v"] = self.buf[nm + ".weight_v"].cpu().clone()
         return sd
 
     def set_batch(self, x: Tensor, y: Tensor):
@@ -154,11 +189,27 @@ class EdEngine:
         self.P.ticked = True
 
     # ---- the step ---------------------------------------------------------------------------------------
+    def _sn_layers(self, with_grad: bool = False):
+        out = []
+        for nm in self.sn_names:
+            ly = dict(w_orig=self.P.p[nm + ".weight"], w_eff=self.w_eff[nm], u=self.buf[nm + ".weight_u"],
+                      v=self.buf[nm + ".weight_v"], sigma=self.sn_sigma[nm])
+            if with_grad:
+                ly["dw"] = self.P.g[nm + ".weight"]
+            out.append(ly)
+        return out
+
+    def _w(self, name: str) -> Tensor:
+        """The weight layer `name` computes with: w_orig / sigma when it is spectrally normalised."""
+        return self.w_eff[name] if name in self.w_eff else self.P.p[name + ".weight"]
+
     def forward(self, train: bool = True):
         P, x = self.P.p, self.x
+        if self.sn_names:          # power iteration (training mode) + effective weights of every normalised layer: one launch
+            ops.spectral_norm_fwd(self._sn_layers(), train)
         for i in range(len(self.chans)):
             pre = f"encoder.conv.{i}.net."
-            ops.conv1d_fwd(x, P[pre + "0.weight"], self.z[i], 1, bias=P[pre + "0.bias"])
+            ops.conv1d_fwd(x, self._w(pre + "0"), self.z[i], 1, bias=P[pre + "0.bias"])
             if train:
                 ops.bn_train_fwd(self.z[i], self.a[i], P[pre + "1.weight"], P[pre + "1.bias"], self.buf[pre + "1.running_mean"],
                                  self.buf[pre + "1.running_var"], self.bn_mean[i], self.bn_invstd[i], act=ACT_GELU)
@@ -170,7 +221,7 @@ class EdEngine:
         ops.linear_fwd(self.pool, P["encoder.project.weight"], self.proj, bias=P["encoder.project.bias"])
         feat = self.proj
         for j in range(len(self.mlp)):
-            ops.linear_fwd(feat, P[f"classifier.net.{3 * j}.weight"], self.ca[j], bias=P[f"classifier.net.{3 * j}.bias"],
+            ops.linear_fwd(feat, self._w(f"classifier.net.{3 * j}"), self.ca[j], bias=P[f"classifier.net.{3 * j}.bias"],
                            zout=self.cz[j], act=ACT_GELU, emul=self.dmask[j] if train else None)
             feat = self.ca[j]
         ops.linear_fwd(feat, P["classifier.head.weight"], self.logits, bias=P["classifier.head.bias"])
@@ -186,11 +237,11 @@ class EdEngine:
         for j in reversed(range(n)):
             jobs.append(ops.linear_wgrad(inp, g, G[wname + ".weight"], db=G[wname + ".bias"], defer=True))
             # d/d(pre-activation) = dropout mask * GELU'(cz)
-            ops.linear_dgrad(g, P[wname + ".weight"], self.dcz[j], gref=self.cz[j], gact=ACT_GELU, emul=self.dmask[j])
+            ops.linear_dgrad(g, self._w(wname), self.dcz[j], gref=self.cz[j], gact=ACT_GELU, emul=self.dmask[j])
             g, wname = self.dcz[j], f"classifier.net.{3 * j}"
             inp = self.ca[j - 1] if j > 0 else self.proj
         jobs.append(ops.linear_wgrad(self.proj, g, G[wname + ".weight"], db=G[wname + ".bias"], defer=True))
-        ops.linear_dgrad(g, P[wname + ".weight"], self.dproj)
+        ops.linear_dgrad(g, self._w(wname), self.dproj)
         jobs.append(ops.linear_wgrad(self.pool, self.dproj, G["encoder.project.weight"], db=G["encoder.project.bias"], defer=True))
         ops.linear_dgrad(self.dproj, P["encoder.project.weight"], self.dpool)
         last = len(self.chans) - 1
@@ -202,8 +253,10 @@ class EdEngine:
             xin = self.a[i - 1] if i > 0 else self.x
             jobs.append(ops.conv1d_wgrad(xin, self.dz[i], G[pre + "0.weight"], 1, db=G[pre + "0.bias"], defer=True))
             if i > 0:
-                ops.conv1d_dgrad(self.dz[i], P[pre + "0.weight"], self.da[i - 1], 1)
+                ops.conv1d_dgrad(self.dz[i], self._w(pre + "0"), self.da[i - 1], 1)
         ops.wgrad_multi(jobs)
+        if self.sn_names:          # the launches above left d w_eff: through w_eff = w_orig / sigma to d w_orig
+            ops.spectral_norm_bwd(self._sn_layers(with_grad=True))
 
     def backward_rng(self):
         self.draw_masks()

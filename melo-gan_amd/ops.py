@@ -598,6 +598,41 @@ def mean_scaled(src, out, scale=1.0):
     L.check(L.load().mg_mean_scaled(_p(src), _p(out), src.numel(), float(scale), _stream()), "mg_mean_scaled")
 
 
+def _sn_jobs(layers, bwd):
+    if not 0 < len(layers) <= L.MAX_SN_JOBS:
+        raise ValueError(f"spectral_norm: 1..{L.MAX_SN_JOBS} layers per launch")
+    arr = (L.SnJob * len(layers))()
+    for a, ly in zip(arr, layers):
+        w, we, u, v, sg = ly["w_orig"], ly["w_eff"], ly["u"], ly["v"], ly["sigma"]
+        rows = w.shape[0]
+        cols = w.numel() // rows
+        _chk(w, "w_orig")
+        _chk(we, "w_eff", tuple(w.shape))
+        _chk(u, "u", (rows,))
+        _chk(v, "v", (cols,))
+        _chk(sg, "sigma", (1,))
+        a.w_orig, a.w_eff, a.u, a.v, a.sigma, a.rows, a.cols = w.data_ptr(), we.data_ptr(), u.data_ptr(), v.data_ptr(), sg.data_ptr(), rows, cols
+        a.dw = None
+        if bwd:
+            _chk(ly["dw"], "dw", tuple(w.shape))
+            a.dw = ly["dw"].data_ptr()
+    return arr
+
+
+def spectral_norm_fwd(layers, train: bool, eps: float = 1e-12):
+    """torch.nn.utils.spectral_norm's weight computation for several layers in one launch (mg_spectral_norm_fwd): layers =
+    dicts of w_orig (out, ...), w_eff (same shape), u (out), v (rest), sigma (1).  train: one power iteration first (u, v
+    updated in place), as the module does in training mode."""
+    arr = _sn_jobs(layers, False)
+    L.check(L.load().mg_spectral_norm_fwd(arr, len(layers), 1 if train else 0, float(eps), _stream()), "mg_spectral_norm_fwd")
+
+
+def spectral_norm_bwd(layers):
+    """layers[i]["dw"] holds the gradient w.r.t. w_eff and leaves holding the gradient w.r.t. w_orig (mg_spectral_norm_bwd)."""
+    arr = _sn_jobs(layers, True)
+    L.check(L.load().mg_spectral_norm_bwd(arr, len(layers), _stream()), "mg_spectral_norm_bwd")
+
+
 def stamp(buf, i: int):
     """buf[i] (int64 device tensor) = the device clock when this node runs (100 MHz ticks)."""
     L.check(L.load().mg_stamp(buf.data_ptr() + 8 * int(i), _stream()), "mg_stamp")
