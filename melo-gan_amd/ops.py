@@ -1379,6 +1379,26 @@ def vae_loss(recon, x, mu, logvar, beta, out, drecon=None, dmu=None, dlv=None):
 # ---------------------------------------------------------------------------------------
 # hipGraph capture + events
 # ---------------------------------------------------------------------------------------
+# Graphs and events still alive at interpreter exit: destroyed from an atexit handler, i.e. while the HIP runtime is still
+# up.  Left to __del__ during interpreter shutdown they may be destroyed after the runtime's own static teardown has begun --
+# a segmentation fault at exit (seen once in ~60 bench runs: the JSON line was out, the exit code was not 0).
+import atexit
+import weakref
+
+_live_handles = weakref.WeakSet()
+
+
+def _release_all():
+    for obj in list(_live_handles):
+        try:
+            obj.release()
+        except Exception:
+            pass
+
+
+atexit.register(_release_all)
+
+
 class Graph:
     """hipGraph captured from whatever is enqueued on PyTorch's current stream between begin() and end(), instantiated
     `execs` times (MELO_GRAPH_EXECS, default 1): launch() goes round the executables.  (Measured: alternating between two or
@@ -1390,6 +1410,7 @@ class Graph:
         self.n = max(1, min(8, int(execs if execs is not None else os.environ.get("MELO_GRAPH_EXECS", "1"))))
         self.handles = (C.c_void_p * self.n)()
         self._next = 0
+        _live_handles.add(self)
 
     def begin(self):
         L.check(L.load().mg_graph_begin(_stream()), "mg_graph_begin")
@@ -1403,11 +1424,15 @@ class Graph:
         self._next = (self._next + 1) % self.n
         L.check(L.load().mg_graph_launch(h, _stream()), "mg_graph_launch")
 
+    def release(self):
+        for i in range(self.n):
+            if self.handles[i]:
+                L.load().mg_graph_destroy(self.handles[i])
+                self.handles[i] = None
+
     def __del__(self):
         try:
-            for h in self.handles:
-                if h:
-                    L.load().mg_graph_destroy(h)
+            self.release()
         except Exception:
             pass
 
@@ -1416,6 +1441,7 @@ class Event:
     def __init__(self):
         self.h = C.c_void_p()
         L.check(L.load().mg_event_create(C.byref(self.h)), "mg_event_create")
+        _live_handles.add(self)
 
     def record(self):
         L.check(L.load().mg_event_record(self.h, _stream()), "mg_event_record")
@@ -1425,8 +1451,13 @@ class Event:
         L.check(L.load().mg_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "mg_event_elapsed_ms")
         return ms.value
 
+    def release(self):
+        if self.h:
+            L.load().mg_event_destroy(self.h)
+            self.h = C.c_void_p()
+
     def __del__(self):
         try:
-            L.load().mg_event_destroy(self.h)
+            self.release()
         except Exception:
             pass
