@@ -477,6 +477,13 @@ int mg_rng_fill_tick(float* normal, long n_normal, float* uniform, long n_unifor
 int mg_rng_fill_tick2(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
                       float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
                       double* adam_state, double* adam_state2, float beta1, float beta2, mg_stream_t stream);
+/* mg_rng_fill_tick2 and mg_stage_rows_cursor (counter = step_counter) as ONE launch: the staging rides as extra block planes.
+ * Both only read the step counter and a fused step needs both first -- one launch and one dependent-launch gap fewer. */
+int mg_rng_fill_tick2_stage(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
+                            float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
+                            double* adam_state, double* adam_state2, float beta1, float beta2, const mg_stage_job* jobs,
+                            int n_jobs, int n_rows, const int64_t* order, long order_len, const uint64_t* base,
+                            mg_stream_t stream);
 
 /* ---- fused flat Adam / AdamW (torch.optim.Adam defaults; src/gan/train_gan.py:136-145,
  *      src/ae/train_ae.py:79).  state: double[4] = {step, beta1^step, beta2^step, unused},

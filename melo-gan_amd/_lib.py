@@ -139,6 +139,7 @@ SIGNATURES = {
     "mg_rng_fill": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp]),
     "mg_rng_fill_tick": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, f32, f32, vp]),
     "mg_rng_fill_tick2": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, vp, f32, f32, vp]),
+    "mg_rng_fill_tick2_stage": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, f32, C.c_uint64, vp, vp, vp, f32, f32, vp, i32, i32, vp, i64, vp, vp]),
     "mg_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp]),
     "mg_adam_flat_ticked": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, vp, vp]),
     "mg_adam_flat_wq": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp, i32, vp, vp, i32, vp]),

@@ -926,10 +926,53 @@ struct RngJobs { RngJob j[4]; int njobs; };
 // these draws is advanced HERE (this kernel does not read it, adam_apply_kernel -- a later launch -- does), and the
 // matching adam_apply advances step_ctr (which only this kernel reads): each of the two launches ticks the counter
 // the OTHER one reads, so neither needs a launch of its own.
+// StageRide (optional): the batch's staging (stage_rows_cursor_kernel's work) as extra blockIdx.y planes of the SAME launch --
+// both only read the step counter, and a fused step needs both before anything else: one launch and one dependent-launch
+// gap fewer at the head of the step.
+struct StageRide { StageJobs J; int n_jobs, n_rows; const int64_t* order; long order_len; const unsigned long long* base; };
+
 __global__ void rng_fill_kernel(const RngJobs jobs, unsigned long long seed, unsigned long long* step_ctr,
-                                double* tick_state, double* tick_state2, double beta1, double beta2) {
+                                double* tick_state, double* tick_state2, double beta1, double beta2, const StageRide sr) {
     const unsigned long long step = step_ctr[0];
     const int jid = blockIdx.y;
+    if (jid >= jobs.njobs) {
+        // a staging plane: the plane's gridDim.x blocks are dealt (row, piece of the row); a thread keeps 8 16-byte loads in
+        // flight (one block walking a 128-KB row 4 KB at a time is 32 dependent round trips: 20 us)
+        const mg_stage_job job = sr.J.j[jid - jobs.njobs];
+        const unsigned long long k = step - sr.base[0];
+        const int per_row = max(1, (int)gridDim.x / sr.n_rows);
+        const int piece = blockIdx.x / sr.n_rows;
+        if (piece >= per_row) return;
+        for (int r = blockIdx.x % sr.n_rows; r < sr.n_rows; r += (int)gridDim.x) {
+            const long pos = (long)((k * (unsigned long long)sr.n_rows + (unsigned long long)r) % (unsigned long long)sr.order_len);
+            long srow = sr.order ? sr.order[pos] : pos;
+            srow = srow < 0 ? 0 : (srow >= job.src_rows ? job.src_rows - 1 : srow);
+            const char* s = static_cast<const char*>(job.src) + srow * job.row_bytes;
+            char* d = static_cast<char*>(job.dst) + (long)r * (job.dst_pitch ? job.dst_pitch : job.row_bytes);
+            if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)job.row_bytes) & 15) == 0) {
+                const long n = job.row_bytes >> 4;
+                const long lo = n * piece / per_row, hi = n * (piece + 1) / per_row;
+                for (long i0 = lo + threadIdx.x; i0 < hi; i0 += 8L * blockDim.x) {
+                    float4 t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const long i = i0 + (long)u * blockDim.x;
+                        t[u] = reinterpret_cast<const float4*>(s)[i < hi ? i : lo];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const long i = i0 + (long)u * blockDim.x;
+                        if (i < hi) reinterpret_cast<float4*>(d)[i] = t[u];
+                    }
+                }
+            } else {
+                const long n = job.row_bytes >> 2;
+                const long lo = n * piece / per_row, hi = n * (piece + 1) / per_row;
+                for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
+            }
+        }
+        return;
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         double* const st[2] = {tick_state, tick_state2};      // one draw may serve two updates (the fused critic + generator step)
         for (int k = 0; k < 2; ++k)
@@ -1557,7 +1600,8 @@ int mg_act_bwd(const float* dy, const float* gref, int gact, const float* emul, 
 
 static int rng_fill_impl(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0,
                          float* mask1, long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter,
-                         double* tick_state, double* tick_state2, float beta1, float beta2, mg_stream_t stream) {
+                         double* tick_state, double* tick_state2, float beta1, float beta2, mg_stream_t stream,
+                         const StageRide* ride = nullptr) {
     MG_CHECK_ARG(step_counter != nullptr, "mg_rng_fill: null step counter");
     MG_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "mg_rng_fill: bad dropout probability");
     RngJobs jobs{};
@@ -1571,11 +1615,17 @@ static int rng_fill_impl(float* normal, long n_normal, float* uniform, long n_un
     add(mask0, n_mask0, 2);
     add(mask1, n_mask1, 2);
     jobs.njobs = n;
-    if (n == 0) return MG_OK;
+    if (n == 0 && !ride) return MG_OK;
+    MG_CHECK_ARG(n > 0, "mg_rng_fill: the staging rider needs at least one tensor to draw");
     unsigned gx = (unsigned)mg_cdiv(mg_cdiv(mx, 4), 256);
     if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(rng_fill_kernel, dim3(gx, n), dim3(256), 0, ST, jobs, (unsigned long long)seed,
-                       (unsigned long long*)step_counter, tick_state, tick_state2, (double)beta1, (double)beta2);
+    StageRide sr{};
+    if (ride) {
+        sr = *ride;
+        if (gx < 256) gx = 256;        // row pieces for the staging planes
+    }
+    hipLaunchKernelGGL(rng_fill_kernel, dim3(gx, n + sr.n_jobs), dim3(256), 0, ST, jobs, (unsigned long long)seed,
+                       (unsigned long long*)step_counter, tick_state, tick_state2, (double)beta1, (double)beta2, sr);
     if (!tick_state)
         hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, ST, (unsigned long long*)step_counter);
     MG_CHECK_LAUNCH("rng_fill");
@@ -1605,6 +1655,29 @@ int mg_rng_fill_tick2(float* normal, long n_normal, float* uniform, long n_unifo
     MG_CHECK_ARG(adam_state && adam_state2 && adam_state != adam_state2, "mg_rng_fill_tick2: two distinct adam states");
     return rng_fill_impl(normal, n_normal, uniform, n_uniform, mask0, n_mask0, mask1, n_mask1, p_drop, seed,
                          step_counter, adam_state, adam_state2, beta1, beta2, stream);
+}
+
+int mg_rng_fill_tick2_stage(float* normal, long n_normal, float* uniform, long n_uniform, float* mask0, long n_mask0, float* mask1,
+                            long n_mask1, float p_drop, uint64_t seed, uint64_t* step_counter, double* adam_state,
+                            double* adam_state2, float beta1, float beta2, const mg_stage_job* jobs, int n_jobs, int n_rows,
+                            const int64_t* order, long order_len, const uint64_t* base, mg_stream_t stream) {
+    MG_CHECK_ARG(adam_state && adam_state2 && adam_state != adam_state2, "mg_rng_fill_tick2_stage: two distinct adam states");
+    MG_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= MG_MAX_STAGE_JOBS && n_rows > 0 && order_len > 0 && base && step_counter,
+                 "mg_rng_fill_tick2_stage: need 1..%d jobs, rows, a positive order length, counter and base", MG_MAX_STAGE_JOBS);
+    StageRide sr{};
+    sr.n_jobs = n_jobs; sr.n_rows = n_rows; sr.order = order; sr.order_len = order_len;
+    sr.base = (const unsigned long long*)base;
+    for (int i = 0; i < n_jobs; ++i) {
+        const mg_stage_job& j = jobs[i];
+        MG_CHECK_ARG(j.src && j.dst && j.row_bytes > 0 && (j.row_bytes & 3) == 0 && j.src_rows > 0 && !j.idx && j.rows == 0 &&
+                         ((((uintptr_t)j.src | (uintptr_t)j.dst)) & 3) == 0 && (order || j.src_rows >= order_len),
+                     "mg_rng_fill_tick2_stage: job %d: the rules of mg_stage_rows_cursor", i);
+        MG_CHECK_ARG(j.dst_pitch == 0 || (j.dst_pitch >= j.row_bytes && (j.dst_pitch & 3) == 0),
+                     "mg_rng_fill_tick2_stage: job %d: dst_pitch must be 0 or a multiple of 4 that holds a row", i);
+        sr.J.j[i] = j;
+    }
+    return rng_fill_impl(normal, n_normal, uniform, n_uniform, mask0, n_mask0, mask1, n_mask1, p_drop, seed, step_counter,
+                         adam_state, adam_state2, beta1, beta2, stream, &sr);
 }
 
 int mg_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,

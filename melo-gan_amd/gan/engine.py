@@ -661,9 +661,14 @@ class GanEngine:
         self._stamp(0)
         # (Tried: the staging launch on the side stream beside the draw -- a fork and a join for two 5-10-us launches: 75.4 k
         # samples/s against 76.2 k without.)
-        self._stage_bound()
+        stage = None
+        if self._bound is not None and os.environ.get("MELO_STAGE_RIDER", "1") == "1":
+            # a bound split: the batch's staging rides in the draw's launch (both only read the step counter)
+            stage = (self._bound, self.B, self.batch_order, self.batch_order_len, self.batch_base)
+        else:
+            self._stage_bound()
         ops.rng_fill(self.noise_2, self.alpha, self.dmask_2[0], self.dmask_2[1], P_DROP, self.rng_seed, self.rng_step,
-                     tick_state=self.D.state, betas=self.betas, tick_state2=self.GE.state)
+                     tick_state=self.D.state, betas=self.betas, tick_state2=self.GE.state, stage=stage)
         self.D.ticked, self.GE.ticked = True, "nobump"
 
     def seed(self, seed: int):

@@ -1236,6 +1236,12 @@ def stage_rows_cursor(jobs, n_rows, order, order_len, counter, base):
         _chk(order, "order", dtype=torch.int64)
         if order.numel() < order_len:
             raise ValueError("stage_rows_cursor: order shorter than order_len")
+    arr = _cursor_jobs(jobs, n_rows, order, order_len)
+    L.check(L.load().mg_stage_rows_cursor(arr, len(jobs), n_rows, _p(order), int(order_len), _p(counter), _p(base), _stream()),
+            "mg_stage_rows_cursor")
+
+
+def _cursor_jobs(jobs, n_rows, order, order_len):
     arr = (L.StageJob * len(jobs))()
     for a, (src, dst) in zip(arr, jobs):
         if not (isinstance(src, torch.Tensor) and src.is_cuda and src.is_contiguous() and src.dim() >= 1):
@@ -1249,8 +1255,7 @@ def stage_rows_cursor(jobs, n_rows, order, order_len, counter, base):
         a.src, a.dst, a.idx = src.data_ptr(), dst.data_ptr(), None
         a.row_bytes, a.src_rows = src.element_size() * (src[0].numel() if src.dim() > 1 else 1), src.shape[0]
         a.dst_pitch, a.rows = 0, 0
-    L.check(L.load().mg_stage_rows_cursor(arr, len(jobs), n_rows, _p(order), int(order_len), _p(counter), _p(base), _stream()),
-            "mg_stage_rows_cursor")
+    return arr
 
 
 def transpose_bcl_blc(x, y, gref=None, gact=ACT_NONE):
@@ -1276,7 +1281,7 @@ def act_bwd(dy, dx, gref=None, gact=ACT_NONE, emul=None):
     L.check(L.load().mg_act_bwd(_p(dy), _p(gref), gact, _p(emul), _p(dx), n, _stream()), "mg_act_bwd")
 
 
-def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_state=None, betas=None, tick_state2=None):
+def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_state=None, betas=None, tick_state2=None, stage=None):
     """normal ~ N(0,1), uniform ~ U(0,1), mask* = keep-mask/(1-p_drop); any of them may be None.  Plain: draw, then
     advance step_counter (two launches).  With tick_state (an optimiser's Adam state) and betas: ONE launch that
     draws and advances that Adam state instead; adam_flat(..., ticked_rng_step=step_counter) later advances the counter."""
@@ -1285,9 +1290,27 @@ def rng_fill(normal, uniform, mask0, mask1, p_drop, seed, step_counter, tick_sta
             _chk(t, "rng tensor")
     _chk(step_counter, "step_counter", (1,), torch.int64)
     n = lambda t: 0 if t is None else t.numel()  # noqa: E731
+    if stage is not None and tick_state2 is None:
+        raise ValueError("rng_fill(stage=...): only with the fused draw (tick_state and tick_state2)")
     if tick_state2 is not None:          # one draw in front of two updates: both Adam states advance here
         _chk(tick_state, "tick_state", (4,), torch.float64)
         _chk(tick_state2, "tick_state2", (4,), torch.float64)
+        if stage is not None:
+            # stage = (jobs, n_rows, order, order_len, base): stage_rows_cursor with counter = step_counter, riding in this launch
+            jobs, n_rows, order, order_len, base = stage
+            if not 0 < len(jobs) <= L.MAX_STAGE_JOBS:
+                raise ValueError(f"rng_fill(stage=...): 1..{L.MAX_STAGE_JOBS} jobs")
+            _chk(base, "base", (1,), torch.int64)
+            if order is not None:
+                _chk(order, "order", dtype=torch.int64)
+                if order.numel() < order_len:
+                    raise ValueError("rng_fill(stage=...): order shorter than order_len")
+            arr = _cursor_jobs(jobs, n_rows, order, order_len)
+            L.check(L.load().mg_rng_fill_tick2_stage(_p(normal), n(normal), _p(uniform), n(uniform), _p(mask0), n(mask0), _p(mask1),
+                                                     n(mask1), p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(step_counter), _p(tick_state),
+                                                     _p(tick_state2), betas[0], betas[1], arr, len(jobs), n_rows, _p(order),
+                                                     int(order_len), _p(base), _stream()), "mg_rng_fill_tick2_stage")
+            return
         L.check(L.load().mg_rng_fill_tick2(_p(normal), n(normal), _p(uniform), n(uniform), _p(mask0), n(mask0), _p(mask1),
                                            n(mask1), p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(step_counter), _p(tick_state),
                                            _p(tick_state2), betas[0], betas[1], _stream()), "mg_rng_fill_tick2")
