@@ -1427,7 +1427,10 @@ class GanEngine:
                                      defer=True))
         big.append(ops.convT1d_wgrad(self.y0, self.d_zd0, GG("decoder.deconv.0.weight"), db=GG("decoder.deconv.0.bias"),
                                      defer=True))
-        tail_fork = self._tail_fork and self.ed_side is not None and self.coll is None
+        # (with the in-graph collectives of data parallelism too: they stay on THIS stream -- one communicator, one stream --
+        # only launches go to the side; decoder.pre.2's gradient is global from the gathered factors, so its share of the
+        # update does not wait for C3)
+        tail_fork = self._tail_fork and self.ed_side is not None
         split = tail_fork and self._ge_head and self.GE.ticked and os.environ.get("MELO_ADAM_SPLIT", "1") == "1"
         cur = torch.cuda.current_stream()
 
