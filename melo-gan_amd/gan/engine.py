@@ -1431,7 +1431,7 @@ class GanEngine:
         # only launches go to the side; decoder.pre.2's gradient is global from the gathered factors, so its share of the
         # update does not wait for C3)
         tail_fork = self._tail_fork and self.ed_side is not None
-        split = tail_fork and self._ge_head and self.GE.ticked and os.environ.get("MELO_ADAM_SPLIT", "1") == "1"
+        split = tail_fork and self._ge_head and self.GE.ticked and os.environ.get("MELO_ADAM_SPLIT", "0") == "1"
         cur = torch.cuda.current_stream()
 
         def side(fn):
@@ -1450,9 +1450,10 @@ class GanEngine:
         side(lambda: ops.wgrad_multi(big, tag="_side2"))
         ops.linear_dgrad(self.d_p2, PG("decoder.pre.2.weight"), self.d_p0, gref=self.a_p0, gact=ACT_RELU)
         if split:
-            # decoder.pre.2's share of the update (89 % of its bytes) leaves the critical path: behind its gradient AND behind
-            # the launch above, the last reader of pre.2's weights in this step (measured: the update behind the
-            # deconvolutions' gradients 0.845, in front of them 0.849 ms per step, same box, four alternations)
+            # MELO_ADAM_SPLIT=1 (off by default): decoder.pre.2's share of the update (89 % of its bytes) as a launch of the side
+            # branch, behind its gradient AND behind the launch above, the last reader of pre.2's weights in this step.  It was
+            # worth 13 us when the tail's side branch was new; since the critic's weight gradients moved into the emotion
+            # branch's stream the undivided update is faster (77.6 k vs 76.7 k samples/s, four alternations)
             side(self._adam_ge_head)
         jobs.append(ops.linear_wgrad(self.lat, self.d_p0, GG("decoder.pre.0.weight"), db=GG("decoder.pre.0.bias"), defer=True))
         jobs.append(ops.linear_wgrad(self.a_n0, self.d_lat, GG("noise_to_latent.net.2.weight"),
