@@ -172,6 +172,10 @@ int mg_conv_thin_dispatch(const float* x, const float* w, float* y, int B, int T
                           int flip, int transposed, int w_sn, int w_sc, long xbs, long ybs, const mg_epilogue* epi,
                           hipStream_t stream);
 
+// conv_mfma.hip: nn.Linear forward on the 64x64-tile window-GEMM kernel (K = 1), output columns in mg_linear_perm's order
+int mg_conv_linear_perm(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, const mg_epilogue* epi,
+                        int perm_L, hipStream_t stream);
+
 // XCD-aware block numbering (cdna_hip_programming.md T1): blocks are observed to be dealt round-robin over the 8 XCDs, each
 // with a private L2, so blocks with equal id % 8 share an L2.  This bijection hands every such group a CONTIGUOUS range
 // of logical ids: blocks that read the same rows get consecutive logical ids and fetch them from memory once per XCD

@@ -59,8 +59,14 @@ struct ConvP {
     float* part;      // [ksplit][B*Tout*N] raw partial sums when ksplit > 1
     void* work;       // caller workspace (may be null)
     size_t work_bytes;
+    int perm_L, perm_C;   // perm_L > 0 (K = 1, Linear forward): output column n is weight row conv_wrow(n) -- mg_linear_perm's order
     mg_epilogue e;
 };
+
+// weight row (and bias / scale / gscale entry) behind output column n
+__device__ __forceinline__ int conv_wrow(const ConvP& p, int n) {
+    return p.perm_L ? (n % p.perm_C) * p.perm_L + n / p.perm_C : n;
+}
 
 // channels per LDS chunk: 16 for K=3/5 taps, 64 for K=1 (Linear layers: fewer, fatter chunks)
 template <int K> struct ChunkOf { static constexpr int value = (K == 1) ? 64 : 16; };
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
             if constexpr (NCK) {
                 // 8 consecutive lanes = 8 consecutive columns, then the quads
                 const int n = (u & 7) + 8 * ((u >> 3) / CG), cg = (u >> 3) % CG;
-                wg[i] = ((unsigned)(n0 + n) * (unsigned)p.w_sn + 4u * cg * K) * 4u;                         // + c0*K per chunk
+                wg[i] = ((unsigned)conv_wrow(p, n0 + n) * (unsigned)p.w_sn + 4u * cg * K) * 4u;             // + c0*K per chunk
                 wl[i] = xs_floats + ((p.flip ? (K - 1) * PK : 0) + cg * PQ) * PP + n * 4;              // + k*wstep per tap
             } else {
                 const int cg = u / (BN * K), e = u - cg * (BN * K);
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                     n = nk / K; k = nk - n * K;
                 }
                 float v = 0.f;
-                if (n0 + n < p.N && c0 + c < c_end) v = p.w[(long)(n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
+                if (n0 + n < p.N && c0 + c < c_end) v = p.w[(long)conv_wrow(p, n0 + n) * p.w_sn + (long)(c0 + c) * p.w_sc + k];
                 smem[xs_floats + ((c >> 2) * PQ + (p.flip ? K - 1 - k : k) * PK) * PP + n * 4 + (c & 3)] = v;
             }
             __syncthreads();
@@ -507,13 +513,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                         if (index(r, di, yi)) dst[di] = a[r];
                     continue;
                 }
+                const int nw = conv_wrow(p, n);          // per-column vectors follow the weight row
                 if (E.bias) {
-                    const float bias = E.bias[n];
+                    const float bias = E.bias[nw];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) a[r] += bias;
                 }
                 if (E.scale) {
-                    const float scale = E.scale[n], shift = E.shift[n];
+                    const float scale = E.scale[nw], shift = E.shift[nw];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) a[r] = a[r] * scale + shift;
                 }
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgemm_kernel(const ConvP p) {
                     for (int r = 0; r < 16; ++r) a[r] *= g[r];
                 }
                 if (E.gscale) {
-                    const float gscale = E.gscale[n];
+                    const float gscale = E.gscale[nw];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) a[r] *= gscale;
                 }
@@ -796,6 +803,25 @@ extern "C" int mg_conv1d_gather(const float* x, const float* w, float* y, int B,
     if (K == 5) return launch_gather<2, 5>(p, s);
     mg_set_error("mg_conv1d_gather: stride 2 needs K=5");
     return MG_EUNSUP;
+}
+
+// nn.Linear forward with mg_linear_perm's output order on the 64x64-tile kernel (K = 1): decoder.pre.2 (512 -> 8192) at the
+// 2B = 128 rows of the fused step, where the skinny kernel's 32x32 tiles re-read the weights four times (linear_skinny.hip
+// routes here; alone 13.2 us against 20.3).  No split-K.
+int mg_conv_linear_perm(const float* x, const float* w, float* y, int M, int K, int N, int w_sn, const mg_epilogue* epi,
+                        int perm_L, hipStream_t stream) {
+    ConvP p{};
+    p.x = x; p.w = w; p.y = y;
+    p.B = M; p.Tin = 1; p.Cin = K; p.Tm = 1; p.Tout = 1; p.N = N;
+    p.xbs = K; p.ybs = N;
+    p.w_sn = w_sn; p.w_sc = 1; p.flip = 0;
+    p.work = nullptr; p.work_bytes = 0;
+    p.perm_L = perm_L > 1 ? perm_L : 0;
+    p.perm_C = p.perm_L ? N / p.perm_L : 0;
+    { const long xb = (long)M * K * 4; p.x_bytes = xb < (1L << 31) ? xb : 0; }
+    { const long wb = ((long)(N - 1) * w_sn + K) * 4; p.w_bytes = wb < (1L << 31) ? wb : 0; }
+    if (int rc = fill_epilogue(p, epi)) return rc;
+    return launch_gather<1, 1>(p, stream);
 }
 
 extern "C" int mg_conv1d_scatter2(const float* x, const float* w, float* y, int B, int Tin, int Cin, int N,
