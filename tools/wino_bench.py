@@ -10,26 +10,7 @@ B, T = 64, 256
 torch.manual_seed(0)
 
 
-def timed(fn, reps=20, inner=20):
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        fn()
-        torch.cuda.synchronize()
-        g = ops.Graph()
-        g.begin()
-        for _ in range(inner):
-            fn()
-        g.end()
-        g.launch()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            g.launch()
-        e1.record()
-        torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (reps * inner)
-
+from _timeit import timeit as timed  # noqa: E402
 
 for name, ci, co in (("conv1", 64, 128), ("conv2", 128, 256), ("conv3", 256, 256)):
     x = torch.randn(B, T, ci).cuda()
