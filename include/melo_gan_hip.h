@@ -225,6 +225,17 @@ int mg_conv1d_wino3_supported(int B, int T, int Cin, int N);
 int mg_wino3_weights(const float* w, float* wt, int N, int Cin, long w_sn, long w_sc, int flip, mg_stream_t stream);
 int mg_conv1d_wino3(const float* x, const float* wt, float* y, int B, int T, int Cin, int N, const mg_epilogue* epi,
                     mg_stream_t stream);
+/* mg_wino3_weights for several filters in ONE launch (a network in training transforms all its layers' weights, forward and
+ * data-gradient images, at the top of every step: emotion_discriminator/engine.py) */
+#define MG_MAX_WINO_WJOBS 8
+typedef struct mg_wino3_wjob {
+    const float* w;
+    float* wt;
+    int N, Cin;
+    long w_sn, w_sc;
+    int flip;
+} mg_wino3_wjob;
+int mg_wino3_weights_multi(const mg_wino3_wjob* jobs, int n_jobs, mg_stream_t stream);
 
 /* Which instantiation of conv_wgemm_kernel<S,K,TR2,TM,TN> a call launches: TM*10+TN (22: 128x128 tile,
  * 12: 64x128, 11: 64x64).  m_rows = B*Tout (gather) or B*Tin (scatter2).  Lets a profiler label

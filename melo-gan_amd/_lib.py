@@ -45,6 +45,13 @@ class StageJob(C.Structure):
 MAX_STAGE_JOBS = 8
 
 
+class WinoWJob(C.Structure):
+    _fields_ = [("w", vp), ("wt", vp), ("N", i32), ("Cin", i32), ("w_sn", i64), ("w_sc", i64), ("flip", i32)]
+
+
+MAX_WINO_WJOBS = 8
+
+
 class SnJob(C.Structure):
     _fields_ = [("w_orig", vp), ("w_eff", vp), ("u", vp), ("v", vp), ("sigma", vp), ("dw", vp), ("rows", i32), ("cols", i32)]
 
@@ -123,6 +130,7 @@ SIGNATURES = {
     "mg_conv1d_wino3_supported": (i32, [i32, i32, i32, i32]),
     "mg_wino3_weights": (i32, [vp, vp, i32, i32, i64, i64, i32, vp]),
     "mg_conv1d_wino3": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "mg_wino3_weights_multi": (i32, [vp, i32, vp]),
     "mg_gp_interp": (i32, [vp, vp, vp, vp, i32, i64, vp]),
     "mg_gp_penalty": (i32, [vp, vp, vp, vp, f32, i32, i64, vp]),
     "mg_wgan_d_loss": (i32, [vp, vp, f32, vp, i32, vp]),

@@ -292,9 +292,50 @@ __global__ void wino3_weights_kernel(const float* __restrict__ w, float* __restr
     wt[o + 3 * ps] = g2;
 }
 
+// several filters in one launch (a network whose weights change every step transforms all its layers at the top of the step)
+struct WinoWJobs { mg_wino3_wjob j[MG_MAX_WINO_WJOBS]; int n; };
+__global__ void wino3_weights_multi_kernel(const WinoWJobs J) {
+    const mg_wino3_wjob q = J.j[blockIdx.y];
+    const long total = (long)q.N * q.Cin;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3);
+        const long r = i >> 2;
+        const int n = (int)(r % q.N);
+        const int cq = (int)(r / q.N);
+        const float* g = q.w + (long)n * q.w_sn + (long)(4 * cq + e) * q.w_sc;
+        const float g0 = g[q.flip ? 2 : 0], g1 = g[1], g2 = g[q.flip ? 0 : 2];
+        const long o = ((long)cq * 4 * q.N + n) * 4 + e;
+        const long ps = (long)q.N * 4;
+        q.wt[o] = g0;
+        q.wt[o + ps] = 0.5f * (g0 + g1 + g2);
+        q.wt[o + 2 * ps] = 0.5f * (g0 - g1 + g2);
+        q.wt[o + 3 * ps] = g2;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mg_wino3_weights_multi(const mg_wino3_wjob* jobs, int n_jobs, mg_stream_t stream) {
+    MG_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= MG_MAX_WINO_WJOBS, "mg_wino3_weights_multi: 1..%d jobs", MG_MAX_WINO_WJOBS);
+    WinoWJobs J{};
+    J.n = n_jobs;
+    long mx = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const mg_wino3_wjob& q = jobs[i];
+        MG_CHECK_ARG(q.w && q.wt && q.N > 0 && q.Cin > 0 && (q.Cin & 3) == 0 && q.w_sn > 0 && q.w_sc > 0,
+                     "mg_wino3_weights_multi: job %d: bad args (Cin must be a multiple of 4)", i);
+        J.j[i] = q;
+        const long t = (long)q.N * q.Cin;
+        mx = t > mx ? t : mx;
+    }
+    long gx = mg_cdiv(mx, 256);
+    gx = gx > 256 ? 256 : gx;
+    hipLaunchKernelGGL(wino3_weights_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, J);
+    MG_CHECK_LAUNCH("wino3_weights_multi");
+    return MG_OK;
+}
 
 int mg_conv1d_wino3_supported(int B, int T, int Cin, int N) {
     if (B <= 0 || T < 2 || (T & 1) || Cin < 16 || (Cin & 15) || N < 64 || (N & 63)) return 0;

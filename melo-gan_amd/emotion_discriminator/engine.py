@@ -61,6 +61,17 @@ class EdEngine:
                 self.buf[k] = torch.ones(s, device=d) if k.endswith("running_var") else torch.zeros(s, device=d)
         self.chans = chans
         self.mlp = tuple(cfg.get("mlp_hidden", (256, 128)))
+        # three-tap layers by minimal filtering (csrc/conv_wino.hip: 2/3 of the direct form's matrix-pipe work) where the
+        # problem is big enough to be bound by it: forward with >= 128 output columns, data-gradient with >= 128 input channels
+        # (the GAN engine's rule); the weights change every step, so both filter images of every such layer are transformed
+        # by ONE launch at the top of the step.  MELO_ED_WINO=0: the direct window GEMMs.
+        import os
+        wino = os.environ.get("MELO_ED_WINO", "1") == "1" and B * T >= 4096
+        self.wino_f = [bool(wino and k == 3 and co >= 128 and ops.wino3_supported(B, T, ci, co)) for (ci, co, k) in chans]
+        self.wino_d = [bool(wino and k == 3 and ci >= 128 and i > 0 and ops.wino3_supported(B, T, co, ci)) for i, (ci, co, k) in enumerate(chans)]
+        wimg = lambda on, cin, n: torch.zeros(cin // 4, 4, n, 4, device=d) if on else None  # noqa: E731
+        self.wino_wf = [wimg(f_, ci, co) for f_, (ci, co, _) in zip(self.wino_f, chans)]
+        self.wino_wd = [wimg(f_, co, ci) for f_, (ci, co, _) in zip(self.wino_d, chans)]
         # spectral normalisation: which layers, their u / v buffers (module state), effective weights and sigmas (derived)
         self.sn_names = []
         if cfg.get("use_spectral_norm", False):
@@ -207,9 +218,21 @@ class EdEngine:
         P, x = self.P.p, self.x
         if self.sn_names:          # power iteration (training mode) + effective weights of every normalised layer: one launch
             ops.spectral_norm_fwd(self._sn_layers(), train)
+        jobs = []
+        for i, (ci, co, _) in enumerate(self.chans):
+            w = self._w(f"encoder.conv.{i}.net.0")
+            if self.wino_f[i]:
+                jobs.append((w, self.wino_wf[i], co, ci, ci * 3, 3, False))
+            if self.wino_d[i] and train:
+                jobs.append((w, self.wino_wd[i], ci, co, 3, ci * 3, True))
+        if jobs:
+            ops.wino3_weights_multi(jobs)
         for i in range(len(self.chans)):
             pre = f"encoder.conv.{i}.net."
-            ops.conv1d_fwd(x, self._w(pre + "0"), self.z[i], 1, bias=P[pre + "0.bias"])
+            if self.wino_f[i]:
+                ops.conv_wino3(x, self.wino_wf[i], self.z[i], bias=P[pre + "0.bias"])
+            else:
+                ops.conv1d_fwd(x, self._w(pre + "0"), self.z[i], 1, bias=P[pre + "0.bias"])
             if train:
                 ops.bn_train_fwd(self.z[i], self.a[i], P[pre + "1.weight"], P[pre + "1.bias"], self.buf[pre + "1.running_mean"],
                                  self.buf[pre + "1.running_var"], self.bn_mean[i], self.bn_invstd[i], act=ACT_GELU)
@@ -252,7 +275,9 @@ class EdEngine:
                              self.bn_invstd[i], G[pre + "1.weight"], G[pre + "1.bias"], act=ACT_GELU, beta=P[pre + "1.bias"])
             xin = self.a[i - 1] if i > 0 else self.x
             jobs.append(ops.conv1d_wgrad(xin, self.dz[i], G[pre + "0.weight"], 1, db=G[pre + "0.bias"], defer=True))
-            if i > 0:
+            if i > 0 and self.wino_d[i]:
+                ops.conv_wino3(self.dz[i], self.wino_wd[i], self.da[i - 1])
+            elif i > 0:
                 ops.conv1d_dgrad(self.dz[i], self._w(pre + "0"), self.da[i - 1], 1)
         ops.wgrad_multi(jobs)
         if self.sn_names:          # the launches above left d w_eff: through w_eff = w_orig / sigma to d w_orig

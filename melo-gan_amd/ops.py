@@ -169,6 +169,21 @@ def wino3_weights(w: Tensor, N: int, Cin: int, w_sn: int, w_sc: int, flip: bool 
     return wt
 
 
+def wino3_weights_multi(jobs):
+    """jobs = [(w, wt, N, Cin, w_sn, w_sc, flip), ...]: the filter transforms of several layers in one launch (wt: existing
+    (Cin/4, 4, N, 4) images)."""
+    if not 0 < len(jobs) <= L.MAX_WINO_WJOBS:
+        raise ValueError(f"wino3_weights_multi: 1..{L.MAX_WINO_WJOBS} jobs")
+    arr = (L.WinoWJob * len(jobs))()
+    for a, (w, wt, N, Cin, w_sn, w_sc, flip) in zip(arr, jobs):
+        _chk(w, "w")
+        _chk(wt, "wt", (Cin // 4, 4, N, 4))
+        if w.numel() < (N - 1) * w_sn + (Cin - 1) * w_sc + 3:
+            raise ValueError("wino3_weights_multi: w smaller than its strides imply")
+        a.w, a.wt, a.N, a.Cin, a.w_sn, a.w_sc, a.flip = w.data_ptr(), wt.data_ptr(), N, Cin, w_sn, w_sc, 1 if flip else 0
+    L.check(L.load().mg_wino3_weights_multi(arr, len(jobs), _stream()), "mg_wino3_weights_multi")
+
+
 def conv_wino3(x: Tensor, wt: Tensor, y: Tensor, **epi) -> Tensor:
     """Stride-1 three-tap convolution (padding 1) through minimal filtering (mg_conv1d_wino3).  x: (B, T, Cin);
     wt: wino3_weights(...) (Cin/4, 4, N, 4); y: (B, T, N)."""

@@ -112,3 +112,20 @@ def test_occupancy_cap_does_not_change_the_result():
         ops.conv_wino3(x, wt, y1)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
+
+
+def test_multi_filter_transform_equals_the_single_launches():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    jobs, want = [], []
+    for (co, ci) in ((128, 64), (256, 128), (256, 256)):
+        w = torch.randn(co, ci, 3, generator=g).cuda()
+        for flip in (False, True):
+            N, Cin, sn, sc = (co, ci, 3 * ci, 3) if not flip else (ci, co, 3, 3 * ci)
+            img = torch.full((Cin // 4, 4, N, 4), float("nan"), device="cuda")
+            jobs.append((w, img, N, Cin, sn, sc, flip))
+            want.append(ops.wino3_weights(w, N, Cin, sn, sc, flip))
+    ops.wino3_weights_multi(jobs)
+    torch.cuda.synchronize()
+    for (_, img, *_), ref in zip(jobs, want):
+        assert torch.equal(img, ref)
