@@ -12,6 +12,10 @@ the gradient all-reduce (N>1) and both Adam updates.  value = N*B*K / max-over-r
 exactly K steps (barrier + synchronize on both sides).  Beside it, "event_timing": every step of a
 second window of max(K, 64) steps between its own pair of HIP events on the engine's stream --
 median / p10 / p90 per step (median of >= 50 hipEvent-timed iterations).
+Behind the W warm-up steps (the first of them eager / capturing, the GPU mostly idle) --settle-steps (default 32) MORE untimed
+steps of the same workload are replayed before the timed window, so that a short window (the driver's K = 20) does not start
+on clocks that are still ramping (0.875 -> 0.825 ms per step over the first ~15 replays, tools/first_steps.py); the line
+reports them as `warmup_settle_steps`.
 
 The same JSON line carries
   roofline     : the dominant kernel SYMBOL (wino3_kernel: the emotion discriminator's three-tap layers by minimal
@@ -56,6 +60,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-steps", type=int, default=32,
+                    help="further untimed steps behind the warm-up, until the GPU's clocks have settled (reported in the line)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the all-cores CPU leg (the 1-thread "
@@ -424,9 +430,18 @@ def main():
             # this script's own collectives stay off the engine's stream (async_op + wait on the process group's stream)
             dist.barrier(async_op=True).wait()
 
+    settle_steps = 0
     with torch.cuda.stream(eng.stream):
         for i in range(max(args.warmup, 3 if use_graph else 1)):
             step(i)
+        # The first warm-up steps are eager / capturing and leave the GPU mostly idle; a timed window that starts right
+        # behind them sees the clocks still ramping (per-step events: 0.875 ms falling to 0.825 over the first ~15 replays
+        # -- tools/first_steps.py).  The metric is steady-state throughput, so --settle-steps MORE untimed steps of the same
+        # workload are replayed first (the same count on every rank); the line reports them (`warmup_settle_steps`).
+        if use_graph and args.settle_steps > 0:
+            for i in range(args.settle_steps):
+                step(i)
+            settle_steps = args.settle_steps
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -623,7 +638,7 @@ def main():
         line = {
             "metric": "piano-roll samples/sec (G+D step), batch=64 128x256 roll",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True,
+            "warmup": args.warmup, "warmup_settle_steps": settle_steps, "ms_per_step": round(1e3 * el / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.ed_dtype == "fp32" else "f32; frozen emotion discriminator stored in bf16 (fp32 accumulate)",
             "data": "synthetic",
