@@ -71,6 +71,7 @@ testable without GPUs.
 from __future__ import annotations
 
 import os
+import sys
 
 MODES = ("auto", "ingraph", "overlap", "gather", "allreduce")
 
@@ -129,8 +130,32 @@ class DataParallel:
             if comm is not None:
                 self.comm = comm
             elif dist is not None and self._backend() == "nccl":
+                # "auto": a private communicator that cannot be created (librccl missing from torch's lib directory, an
+                # id exchange that fails) must not take the job down -- every rank then agrees on the round-2 order over
+                # torch.distributed.  MELO_DP_MODE=ingraph asks for it explicitly and gets the error.
                 from .rccl import RcclComm
-                self.comm = RcclComm.from_process_group(dist, group)
+                err = None
+                try:
+                    self.comm = RcclComm.from_process_group(dist, group)
+                except Exception as ex:      # noqa: BLE001
+                    err = ex
+                ok = torch_ok = 1 if err is None else 0
+                try:
+                    import torch
+                    t = torch.tensor([ok], device="cuda", dtype=torch.int32)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                    torch_ok = int(t.item())
+                except Exception:            # noqa: BLE001
+                    pass
+                if err is not None and self.mode == "ingraph":
+                    raise err
+                if not torch_ok:             # some rank failed: nobody uses the private communicator
+                    if self.comm is not None:
+                        self.comm.destroy()
+                        self.comm = None
+                    if err is not None:
+                        print(f"[melo_gan_amd.dp] in-graph collectives unavailable ({err}); falling back to the torch.distributed "
+                              "step order", file=sys.stderr)
             elif self.mode == "ingraph":
                 raise ValueError("MELO_DP_MODE=ingraph needs the nccl (RCCL) backend or an explicit communicator")
         if self.comm is not None:
