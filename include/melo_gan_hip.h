@@ -144,9 +144,25 @@ typedef struct mg_conv16_extra {
     const float* mix_alpha;
     float* mix_out;
     int mix_rows;
+    /* bnb_*: the launch's output y is the gradient that reaches a train-mode BatchNorm + ReLU / LeakyReLU layer from above
+     * (src/gan/models.py:57-61 backwards); with that layer's forward tensors a, z (laid out like y) and saved statistics it also
+     * leaves bnb_part[p][0][n] = sum_rows g, [1][n] = sum_rows g * x_hat (g = y * act'(a), x_hat = (z - mean) * invstd; p, rows
+     * as for `part`: 2 * part_rows * N DOUBLES, accumulated in fp64 like the reduction pass they replace), so the BatchNorm's
+     * backward is ONE launch, mg_bn_train_bwd_parts */
+    const float* bnb_a;
+    const float* bnb_z;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    double* bnb_part;
+    int bnb_act;
 } mg_conv16_extra;
 int mg_conv16_ex(const float* x, const float* wq, float* y, int B, int Tin, int Cin, int N, int transposed, int Tout,
                  long xbs, long ybs, const mg_epilogue* epi, const mg_conv16_extra* extra, mg_stream_t stream);
+/* mg_bn_train_bwd behind a conv16 launch that left the two column sums (bnb_part, part_rows rows of 2 x C doubles): the sums
+ * are added in row order and the gradient applied -- one launch. */
+int mg_bn_train_bwd_parts(const double* part, int part_rows, const float* da, const float* a, const float* z, float* dz, long R,
+                          int C, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                          float* dgamma, float* dbeta, int act, mg_stream_t stream);
 int mg_bn_train_fwd_parts(const float* part, int part_rows_per_group, int groups, const float* z, float* a, long R, int C,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                           float eps, float* save_mean, float* save_invstd, int act, mg_stream_t stream);

@@ -25,7 +25,8 @@ class EpilogueBf16(C.Structure):
 
 class Conv16Extra(C.Structure):
     _fields_ = [("part", vp), ("pool", vp), ("pool_scale", f32), ("y_perm", i32), ("mix_real", vp), ("mix_alpha", vp),
-                ("mix_out", vp), ("mix_rows", i32)]
+                ("mix_out", vp), ("mix_rows", i32), ("bnb_a", vp), ("bnb_z", vp), ("bnb_mean", vp), ("bnb_invstd", vp),
+                ("bnb_part", vp), ("bnb_act", i32)]
 
 
 class ChainOp(C.Structure):
@@ -110,6 +111,7 @@ SIGNATURES = {
     "mg_bn_groups_workspace_bytes": (sz, [i32, i32]),
     "mg_bn_train_fwd_groups": (i32, [vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, i32, vp, sz, vp]),
     "mg_bn_train_bwd": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "mg_bn_train_bwd_parts": (i32, [vp, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "mg_bn_eval_fwd": (i32, [vp, vp, i64, i32, vp, vp, vp, vp, f32, i32, vp]),
     "mg_bn_fold": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, vp]),
     "mg_meanT_fwd": (i32, [vp, vp, i32, i32, i32, vp]),

@@ -56,6 +56,16 @@ struct Conv16P {
     const float* mix_alpha;
     float* mix_out;
     int mix_rows;
+    // bnb: the launch's output is the gradient dy that reaches a train-mode BatchNorm + ReLU / LeakyReLU from above; with the
+    // layer's forward tensors a (activation) and z (BatchNorm input) it also leaves the two per-column sums the BatchNorm's
+    // backward needs -- bnb_part[(2*mtile + wm)][0][n] = sum g, [1][n] = sum g * x_hat, g = dy * act'(a), x_hat = (z - mean) * invstd
+    // -- so that backward is ONE launch (mg_bn_train_bwd_parts) instead of a reduction pass plus an apply pass
+    const float* bnb_a;
+    const float* bnb_z;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    double* bnb_part;
+    int bnb_act;
 };
 
 constexpr int K5 = 5;
@@ -251,6 +261,8 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
     const float scale = E.scale ? E.scale[n] : 1.f, shift = E.scale ? E.shift[n] : 0.f;
     const float gscale = E.gscale ? E.gscale[n] : 1.f;
     float st1 = 0.f, cnt = 0.f;
+    double bs1 = 0.0, bs2 = 0.0;        // fp64 like the reduction pass they replace (a handful of values per lane)
+    const float bnb_mu = (RID && p.bnb_part) ? p.bnb_mean[n] : 0.f, bnb_is = (RID && p.bnb_part) ? p.bnb_invstd[n] : 0.f;
     const bool want_stats = RID && (p.part || p.pool);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -341,6 +353,21 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (ok[r]) p.y[yi[r]] = a[r];
+            if (RID && p.bnb_part) {      // operands loaded unconditionally (row-clamped), all in flight, like gref
+                float av[4], zv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    av[r] = p.bnb_a[ok[r] ? di[r] : 0u];
+                    zv[r] = p.bnb_z[ok[r] ? di[r] : 0u];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[r]) {
+                        const double gy = (double)(a[r] * mg_act_grad(p.bnb_act, av[r]));
+                        bs1 += gy;
+                        bs2 += gy * (((double)zv[r] - (double)bnb_mu) * (double)bnb_is);
+                    }
+            }
             if (RID && p.mix_out) {
                 float rv[4], al[4];
 #pragma unroll
@@ -353,6 +380,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16P p) {
                     if (mixrow[r]) p.mix_out[yi[r]] = fmaf(al[r], rv[r], (1.f - al[r]) * a[r]);
             }
         }
+    if (RID && p.bnb_part) {      // the four lanes of a column -> one partial pair per wave and column
+        bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
+        bs2 += __shfl_xor(bs2, 16, 64); bs2 += __shfl_xor(bs2, 32, 64);
+        if (kq == 0) {
+            double* dst = p.bnb_part + (long)(2 * blockIdx.x + wm) * 2 * p.N + n;
+            dst[0] = bs1;
+            dst[p.N] = bs2;
+        }
+    }
     if (want_stats) {        // the four lanes of a column (row groups kq = 0..3) -> one partial per wave and column
         st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
         if (kq == 0 && p.pool && 2 * (int)blockIdx.x + wm < p.B) p.pool[(long)(2 * blockIdx.x + wm) * p.N + n] = st1 * p.pool_scale;
@@ -559,10 +595,16 @@ static int conv16_launch(const float* x, const float* wq, float* y, int B, int T
     p.y_perm = ex.y_perm ? 1 : 0;
     p.mix_real = ex.mix_real; p.mix_alpha = ex.mix_alpha; p.mix_out = ex.mix_out;
     p.mix_rows = ex.mix_out ? ex.mix_rows : 0;
+    MG_CHECK_ARG(!ex.bnb_part || (ex.bnb_a && ex.bnb_z && ex.bnb_mean && ex.bnb_invstd && !ex.y_perm && !(epi && epi->accumulate) &&
+                                  (ex.bnb_act == MG_ACT_RELU || ex.bnb_act == MG_ACT_LRELU)),
+                 "mg_conv16: the BatchNorm-backward sums need a, z, mean, invstd, a ReLU / LeakyReLU layer, the plain output "
+                 "order and a non-accumulating launch");
+    p.bnb_a = ex.bnb_a; p.bnb_z = ex.bnb_z; p.bnb_mean = ex.bnb_mean; p.bnb_invstd = ex.bnb_invstd; p.bnb_part = (double*)ex.bnb_part;
+    p.bnb_act = ex.bnb_act;
     hipStream_t s = (hipStream_t)stream;
     const int rt = pick_rt((long)B * Tm, N);
     int rc;
-    const bool rid = p.part || p.pool || p.y_perm || p.mix_out;
+    const bool rid = p.part || p.pool || p.y_perm || p.mix_out || p.bnb_part;
     if (rid) {
         if (transposed) rc = rt == 2 ? launch16<true, 2, true>(p, s) : launch16<true, 1, true>(p, s);
         else rc = rt == 2 ? launch16<false, 2, true>(p, s) : launch16<false, 1, true>(p, s);

@@ -345,7 +345,8 @@ __global__ __launch_bounds__(BNA_THREADS) void bn_parts_apply_kernel(const PT* _
 // BatchNorm backward, second (last) launch: every block sums ITS 64 channels' fp64 partials of colsum_partial_kernel<1>
 // (fixed order), then applies to its row slice; row slice 0 also writes dgamma / dbeta.  (Was a finishing launch + an apply
 // launch.)
-__global__ __launch_bounds__(BNA_THREADS) void bn_bwd_parts_apply_kernel(const double* __restrict__ part, int nsplit, int C, long R,
+template <typename PT>
+__global__ __launch_bounds__(BNA_THREADS) void bn_bwd_parts_apply_kernel(const PT* __restrict__ part, int nsplit, int C, long R,
                                                                  const float* __restrict__ da, const float* __restrict__ a,
                                                                  const float* __restrict__ z, float* __restrict__ dz,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(BNA_THREADS) void bn_bwd_parts_apply_kernel(const d
         double t1 = 0.0, t2 = 0.0;
         if (c0 + cx < C)
             for (int q0 = pl; q0 < nsplit; q0 += 8 * BNA_PL) {
-                double va[8], vb[8];
+                PT va[8], vb[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int q = q0 + BNA_PL * j;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(BNA_THREADS) void bn_bwd_parts_apply_kernel(const d
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (q0 + BNA_PL * j < nsplit) { t1 += va[j]; t2 += vb[j]; }
+                    if (q0 + BNA_PL * j < nsplit) { t1 += (double)va[j]; t2 += (double)vb[j]; }
             }
         sh[pl][cx] = t1;
         sh[BNA_PL + pl][cx] = t2;
@@ -1326,9 +1327,27 @@ int mg_bn_train_bwd(const float* da, const float* a, const float* z, float* dz, 
     if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
     const long rows_per = mg_cdiv(R, slices);
     slices = mg_cdiv(R, rows_per);
-    hipLaunchKernelGGL(bn_bwd_parts_apply_kernel, dim3((unsigned)cb, (unsigned)slices), dim3(BNA_THREADS), 0, ST, (const double*)part,
+    hipLaunchKernelGGL(bn_bwd_parts_apply_kernel<double>, dim3((unsigned)cb, (unsigned)slices), dim3(BNA_THREADS), 0, ST, (const double*)part,
                        pl.nsplit, C, R, da, a, z, dz, gamma, beta, save_mean, save_invstd, dgamma, dbeta, act, rows_per);
     MG_CHECK_LAUNCH("bn_train_bwd");
+    return MG_OK;
+}
+
+int mg_bn_train_bwd_parts(const double* part, int part_rows, const float* da, const float* a, const float* z, float* dz, long R,
+                          int C, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                          float* dgamma, float* dbeta, int act, mg_stream_t stream) {
+    MG_CHECK_ARG(part && part_rows > 0 && da && a && z && dz && gamma && save_mean && save_invstd && dgamma && dbeta && R > 0 && C > 0,
+                 "mg_bn_train_bwd_parts: bad args");
+    MG_CHECK_ARG(act == MG_ACT_RELU || act == MG_ACT_LRELU, "mg_bn_train_bwd_parts: ReLU / LeakyReLU layers only");
+    const long cb = mg_cdiv(C, 64);
+    long slices = 256 / cb;
+    if (slices < 1) slices = 1;
+    if (slices > mg_cdiv(R, 64)) slices = mg_cdiv(R, 64);
+    const long rows_per = mg_cdiv(R, slices);
+    slices = mg_cdiv(R, rows_per);
+    hipLaunchKernelGGL(bn_bwd_parts_apply_kernel<double>, dim3((unsigned)cb, (unsigned)slices), dim3(BNA_THREADS), 0, ST, part, part_rows,
+                       C, R, da, a, z, dz, gamma, beta, save_mean, save_invstd, dgamma, dbeta, act, rows_per);
+    MG_CHECK_LAUNCH("bn_train_bwd_parts");
     return MG_OK;
 }
 

@@ -431,10 +431,10 @@ class GanEngine:
 
     class _Riders:
         """What a _conv5s2 launch did besides the convolution (the caller runs a separate kernel for what it did not)."""
-        __slots__ = ("parts", "pooled", "perm", "mixed")
+        __slots__ = ("parts", "pooled", "perm", "mixed", "bnb")
 
         def __init__(self):
-            self.parts, self.pooled, self.perm, self.mixed = None, False, False, False
+            self.parts, self.pooled, self.perm, self.mixed, self.bnb = None, False, False, False, None
 
     def _tick(self):
         """Interleaved capture of the forked step graph (dg_fork_step_rng): after a main-branch convolution launch, issue the
@@ -446,7 +446,7 @@ class GanEngine:
                     self._il = None
 
     def _conv5s2(self, kind: str, x: Tensor, fp: "FlatParams", name: str, y: Tensor, stats=None, pool=None, perm=False,
-                 mix=None, **epi):
+                 mix=None, bnb=None, **epi):
         """One stride-2 five-tap convolution launch.  kind: conv_fwd / conv_dgrad (nn.Conv1d, weight (Cout,Cin,5)) or
         convT_fwd / convT_dgrad (nn.ConvTranspose1d, weight (Cin,Cout,5)).  conv16 (no split-K, no finish launch) wherever
         it covers the shape (faster on every cfg2 layer, tools/conv16_bench.py); the 64x64-tile kernel otherwise.
@@ -456,7 +456,9 @@ class GanEngine:
           pool = (B, N) tensor: the temporal mean of the output -> .pooled;
           perm: y is (B, N, Tout), the order of the Linear output the reference views as (B, C, L) -> .perm; when the
                 launch cannot, NOTHING is launched and the caller takes its two-launch route;
-          mix = (real, alpha, out, rows): the gradient penalty's interpolate of the first `rows` samples -> .mixed."""
+          mix = (real, alpha, out, rows): the gradient penalty's interpolate of the first `rows` samples -> .mixed;
+          bnb = (a, z, mean, invstd, act): y is the gradient reaching a train-mode BatchNorm layer: the two column sums of its
+                backward -> .bnb = (part, part_rows) (ops.bn_train_bwd_parts is then ONE launch)."""
         w = fp.p[name]
         res = GanEngine._Riders()
         transposed = kind in ("conv_dgrad", "convT_fwd")
@@ -479,6 +481,11 @@ class GanEngine:
                     res.parts = (part, rows)
             if perm:
                 kw["perm"] = res.perm = True
+            if bnb is not None and y.shape[1] == (2 * Tin if transposed else (Tin + 4 - 5) // 2 + 1):
+                rows = ops.conv16_plan(B, Tin, N, transposed)[1]
+                bpart = ops.workspace(16 * rows * N, x.device, "bnb_part").view(torch.float64)
+                kw["bnb"] = (bnb[0], bnb[1], bnb[2], bnb[3], bpart, bnb[4])
+                res.bnb = (bpart, rows)
             if mix is not None:
                 kw["mix"] = mix
                 res.mixed = True
@@ -1382,14 +1389,22 @@ class GanEngine:
         if self.dn_dense is not None:      # zero-padded tail rows carry no gradient (models.py:78-81)
             ops.copy_cols(self.dnotes.view(B, -1), 0, self.dn_dense.view(B, -1), 0, self.L3 * self.C)
             dn = self.dn_dense
-        self._conv5s2("convT_dgrad", dn, self.GE, "G.decoder.deconv.6.weight", self.d_ad3)
-        ops.bn_train_bwd(self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, PG("decoder.deconv.4.weight"), self.bn_mean[1],
-                         self.bn_invstd[1], GG("decoder.deconv.4.weight"), GG("decoder.deconv.4.bias"), ACT_RELU)
-        self._conv5s2("convT_dgrad", self.d_zd3, self.GE, "G.decoder.deconv.3.weight", self.d_ad0)
-        ops.bn_train_bwd(self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, PG("decoder.deconv.1.weight"), self.bn_mean[0],
-                         self.bn_invstd[0], GG("decoder.deconv.1.weight"), GG("decoder.deconv.1.bias"), ACT_RELU)
-        # (Leaving BatchNorm backward's two column sums to the producing conv16 launch as well was built and measured:
-        #  its epilogue then reads a and z, scattered and exposed at the kernel's tail -- no faster than the reduction pass.)
+        # BatchNorm backward: the two column sums ride in the data-gradient launch that produces the incoming gradient (conv16's
+        # bnb rider), so the BatchNorm's own backward is ONE launch instead of a reduction pass plus an apply pass.  (Round 2
+        # measured the rider as "no faster than the reduction pass" when that pass cost one of three launches; with two
+        # launches of ~8 us at the dependent-launch floor on the tail's critical path it is -- MELO_BNB_RIDER=0: the old path.)
+        rider = os.environ.get("MELO_BNB_RIDER", "1") == "1"
+        for (dy_src, wname, da, a_, z_, dz_, bn, i) in (
+                (dn, "G.decoder.deconv.6.weight", self.d_ad3, self.a_d3, self.z_d3, self.d_zd3, "decoder.deconv.4", 1),
+                (self.d_zd3, "G.decoder.deconv.3.weight", self.d_ad0, self.a_d0, self.z_d0, self.d_zd0, "decoder.deconv.1", 0)):
+            r = self._conv5s2("convT_dgrad", dy_src, self.GE, wname, da,
+                              bnb=(a_, z_, self.bn_mean[i], self.bn_invstd[i], ACT_RELU) if rider else None)
+            if r.bnb is not None:
+                ops.bn_train_bwd_parts(r.bnb[0], r.bnb[1], da, a_, z_, dz_, PG(bn + ".weight"), self.bn_mean[i], self.bn_invstd[i],
+                                       GG(bn + ".weight"), GG(bn + ".bias"), ACT_RELU)
+            else:
+                ops.bn_train_bwd(da, a_, z_, dz_, PG(bn + ".weight"), self.bn_mean[i], self.bn_invstd[i], GG(bn + ".weight"),
+                                 GG(bn + ".bias"), ACT_RELU)
         # times pre.2's relu' (mask from y0 = its output as the deconvolution read it), stored in the reference's
         # (B, 256*red) order: the launch writes (b, c, l) itself where conv16 runs it, else a transpose follows
         if not self._conv5s2("convT_dgrad", self.d_zd0, self.GE, "G.decoder.deconv.0.weight", self.d_p2.view(B, 256, self.red),

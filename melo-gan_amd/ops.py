@@ -307,7 +307,7 @@ def _conv16_plan(B, Tin, N, transposed):
 
 
 def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool = False, stats=None, pool=None,
-           perm: bool = False, mix=None, **epi) -> Tensor:
+           perm: bool = False, mix=None, bnb=None, **epi) -> Tensor:
     """Stride-2 K=5 window GEMM on 16x16 MFMA tiles with WQ-layout weights (mg_conv16_ex).  transposed=False: the gather
     form (Conv1d forward / ConvTranspose1d data-gradient), True: the scatter form (ConvTranspose1d forward / Conv1d
     data-gradient; odd: Tout = 2*Tin - 1).  y: (B, Ty >= Tout, N).  Riders of the same launch:
@@ -316,7 +316,10 @@ def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool
       pool = (tensor (B, N), scale): the temporal mean of the output (gather form, conv16_poolable shapes);
       perm: y is (B, N, Tout) -- i.e. the (B, N*Tout) matrix a Linear produced and the reference views as (B, N, L);
       mix = (real, alpha, out, rows): out[b] = alpha[b] * real[b] + (1 - alpha[b]) * y[b] for b < rows (tensors laid out
-            like y): the gradient penalty's interpolate."""
+            like y): the gradient penalty's interpolate;
+      bnb = (a, z, mean, invstd, part, act): y is the gradient reaching a train-mode BatchNorm + ReLU / LeakyReLU layer whose
+            forward tensors are a, z (like y): part (2 * part_rows * N float64, conv16_plan) receives the two column sums its
+            backward needs (bn_train_bwd_parts then is one launch)."""
     _chk(x, "x")
     _chk(wq, "wq")
     _chk(y, "y")
@@ -351,6 +354,18 @@ def conv16(x: Tensor, wq: Tensor, y: Tensor, N: int, transposed: bool, odd: bool
             raise ValueError(f"conv16: shape B={B} Tin={Tin} Cin={Cin} N={N} is not poolable")
         ex.pool, ex.pool_scale = _p(pt), float(scale)
     ex.y_perm = 1 if perm else 0
+    if bnb is not None:
+        ba, bz, bmean, binv, bpart, bact = bnb
+        if perm or Ty != Tout:
+            raise ValueError("conv16: bnb needs the plain, dense output")
+        _chk(ba, "bnb a", (B, Tout, N))
+        _chk(bz, "bnb z", (B, Tout, N))
+        _chk(bmean, "bnb mean", (N,))
+        _chk(binv, "bnb invstd", (N,))
+        _chk(bpart, "bnb part", dtype=torch.float64)
+        if bpart.numel() < 2 * conv16_plan(B, Tin, N, transposed)[1] * N:
+            raise ValueError("conv16: bnb partial buffer too small (2 * part_rows * N doubles)")
+        ex.bnb_a, ex.bnb_z, ex.bnb_mean, ex.bnb_invstd, ex.bnb_part, ex.bnb_act = _p(ba), _p(bz), _p(bmean), _p(binv), _p(bpart), int(bact)
     if mix is not None:
         real, alpha, out, rows = mix
         if perm or not 0 < rows <= B:
@@ -967,6 +982,24 @@ def bn_train_bwd(da, a, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta, act
         _chk(beta, "beta", (Cc,))
     L.check(lib.mg_bn_train_bwd(_p(da), _p(a), _p(z), _p(dz), R, Cc, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
                                 _p(dgamma), _p(dbeta), act, _p(work), work.numel(), _stream()), "mg_bn_train_bwd")
+    return dz
+
+
+def bn_train_bwd_parts(part, part_rows, da, a, z, dz, gamma, save_mean, save_invstd, dgamma, dbeta, act=ACT_RELU):
+    """bn_train_bwd behind a conv16 launch that left the two column sums in `part` (conv16(bnb=...)): ONE launch."""
+    _chk(part, "part", dtype=torch.float64)
+    _chk(da, "da", z.shape)
+    _chk(a, "a", z.shape)
+    _chk(z, "z")
+    _chk(dz, "dz", z.shape)
+    Cc = z.shape[-1]
+    R = z.numel() // Cc
+    if part.numel() < 2 * part_rows * Cc:
+        raise ValueError("bn_train_bwd_parts: partial buffer too small")
+    for nm, v in (("gamma", gamma), ("save_mean", save_mean), ("save_invstd", save_invstd), ("dgamma", dgamma), ("dbeta", dbeta)):
+        _chk(v, nm, (Cc,))
+    L.check(L.load().mg_bn_train_bwd_parts(_p(part), part_rows, _p(da), _p(a), _p(z), _p(dz), R, Cc, _p(gamma), None, _p(save_mean),
+                                           _p(save_invstd), _p(dgamma), _p(dbeta), act, _stream()), "mg_bn_train_bwd_parts")
     return dz
 
 

@@ -254,3 +254,41 @@ def test_linear_with_permuted_output_columns(ops, M, K, Cc, Lp):
         assert torch.equal(z, ref.view(M, Cc, Lp).permute(0, 2, 1).contiguous())
     want = (x.double() @ w.double().t() + b.double()).view(M, Cc, Lp).permute(0, 2, 1)
     assert ((z.double() - want).norm() / want.norm()).item() < 2e-6
+
+
+@pytest.mark.parametrize("B,L,Cin,N", [(64, 128, 128, 64), (64, 64, 64, 128), (3, 16, 16, 32)])
+def test_batchnorm_backward_sums_ride_in_the_data_gradient_launch(ops, B, L, Cin, N):
+    """conv16(bnb=...): the launch that produces the gradient reaching a train-mode BatchNorm + ReLU layer also leaves the two
+    column sums of that layer's backward; bn_train_bwd_parts (one launch) then equals bn_train_bwd (reduction + apply) -- and
+    autograd in fp64."""
+    g = torch.Generator().manual_seed(B + L + Cin + N)
+    # gather form: y (B, L/2... ) -- use the generator's data-gradient shape: x (B, L, Cin) -> y (B, L//2, N) via conv16 gather
+    x = torch.randn(B, L, Cin, generator=g).cuda()
+    w = (torch.randn(N, Cin, 5, generator=g) * 0.05).cuda()
+    wq = torch.zeros(N * Cin * 5, device="cuda")
+    ops.wq_relayout(w, wq, N, Cin, 5, Cin * 5, 5)
+    Tout = L // 2
+    z = torch.randn(B, Tout, N, generator=g).cuda()
+    gamma, beta = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    a = torch.empty_like(z)
+    mean, invstd = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    ops.bn_train_fwd(z, a, gamma, beta, None, None, mean, invstd, ops.ACT_RELU, 0.1, 1e-5)
+    _, rows = ops.conv16_plan(B, L, N, False)
+    part = torch.full((2 * rows * N,), float("nan"), device="cuda", dtype=torch.float64)
+    dy = torch.empty(B, Tout, N, device="cuda")
+    ops.conv16(x, wq, dy, N, False, bnb=(a, z, mean, invstd, part, ops.ACT_RELU))
+    dy0 = torch.empty_like(dy)
+    ops.conv16(x, wq, dy0, N, False)
+    assert torch.equal(dy, dy0)                                  # the rider does not touch the output
+    dz1, dg1, db1 = torch.empty_like(z), torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    ops.bn_train_bwd_parts(part, rows, dy, a, z, dz1, gamma, mean, invstd, dg1, db1, ops.ACT_RELU)
+    dz2, dg2, db2 = torch.empty_like(z), torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    ops.bn_train_bwd(dy, a, z, dz2, gamma, mean, invstd, dg2, db2, ops.ACT_RELU)
+    torch.cuda.synchronize()
+    rel = lambda p_, q_: ((p_.double() - q_.double()).norm() / (q_.double().norm() + 1e-30)).item()  # noqa: E731
+    assert rel(dz1, dz2) < 2e-6 and rel(dg1, dg2) < 2e-6 and rel(db1, db2) < 2e-6
+    z64 = z.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yy = torch.relu(torch.nn.functional.batch_norm(z64.reshape(-1, N), None, None, g64, b64, True, 0.1, 1e-5)).reshape(B, Tout, N)
+    (yy * dy.double()).sum().backward()
+    assert rel(dz1, z64.grad) < 2e-5 and rel(dg1, g64.grad) < 2e-5 and rel(db1, b64.grad) < 2e-5
